@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: input Msamples/s through FIR-decimate + FM demod.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one 20 MS/s stream of 2^30 synthetic int16 IQ samples
+resident in HBM, 64-tap Hann low-pass, decimate by 10, quadrature discriminator -> float32.
+A "step" is one pass of the fused HIP kernel over the whole 2^30-sample block.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the stream is N * 2^30 samples and
+rank r owns time block r with its FIR history halo resident -- no collective in the
+timed loop, scaling "weak".  The final RCCL gather of the decimated outputs to rank 0 runs once
+after the timed steps and is reported separately (gather_ms).
+
+The JSON line carries `roofline` (HIP-event time of the kernel itself, measured on the launch
+stream, against the 8 TB/s HBM peak with 4.4 algorithmic bytes per input sample) and, at N = 1,
+`cpu_baseline` (the reference's own chain from oracle/_ref timed on this box's host, one thread).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=30, help="samples per GPU = 2^log2n")
+    ap.add_argument("--taps", type=int, default=64)
+    ap.add_argument("--decim", type=int, default=10)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--outputs-per-lane", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--no-gather", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(O, taps, D, budget_s):
+    """reference chain (scale -> polyphase_decimate -> polar_discriminator), one host thread, on a
+    bounded sample of the same synthetic signal"""
+    n = 1 << 24
+    iq = O.synth_fm_i16(n, fs=20.0e6, ftone=1000.0, dev=5000.0, amp=2000.0)
+    scale = 1.0 / (2.0 * np.pi)
+    if O.have_ref():
+        kind = "reference"
+        t1 = O.ref_time_chain_i16(iq, D, taps, O.MODE_FM, scale, 1)
+        reps = max(1, int(budget_s / max(t1, 1e-3)) - 1)
+        t = O.ref_time_chain_i16(iq, D, taps, O.MODE_FM, scale, reps)
+    else:
+        kind = "port"
+        t0 = time.perf_counter()
+        O.chain_i16(iq, D, taps, O.MODE_FM, scale)
+        t1 = time.perf_counter() - t0
+        reps = max(1, int(budget_s / max(t1, 1e-3)) - 1)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            O.chain_i16(iq, D, taps, O.MODE_FM, scale)
+        t = time.perf_counter() - t0
+    return {"value": round(n * reps / t / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "sample": f"{reps} passes over the first 2^24 samples of the same synthetic FM stream, "
+                      f"{t:.1f} s, float64 as the reference, host nproc={os.cpu_count()}"}
+
+
+def main():
+    a = parse()
+    import torch
+    import sdr_amd
+    from oracle import oracle as O
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    assert world == a.gpus or world == 1, (world, a.gpus)
+    dev = torch.device("cuda", local)
+    sdr_amd.init(local)
+
+    D, T = a.decim, a.taps
+    n_blk = 1 << a.log2n                       # samples per GPU
+    n_total = n_blk * world
+    taps = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")     # cutoff at the decimated Nyquist
+    plan = sdr_amd.FirPlan(taps, D, mode=sdr_amd.MODE_FM, scale=1.0 / (2.0 * np.pi),
+                           outputs_per_lane=a.outputs_per_lane, threads=a.threads)
+    cnt_total = plan.out_count(n_total)
+    ob = cnt_total * rank // world             # this rank's slice of the final output
+    oe = cnt_total * (rank + 1) // world
+    lo = max(0, ob * D - (T - 1))              # resident window = own block + FIR history halo
+    hi = min(n_total, (oe + 1) * D + 1)
+    n_res = hi - lo
+
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(2 * n_res + 8, dtype=torch.int16, device=dev)
+    d_out = torch.empty(oe - ob + 8, dtype=torch.float32, device=dev)
+    sdr_amd.capi.synth_fm_i16_dev(d_in, n_res, n0=lo, fs=20.0e6, ftone=1000.0, dev=5000.0,
+                                  amp=2000.0, noise_lsb=0, seed=1, stream=st)
+    torch.cuda.synchronize()
+
+    def step():
+        plan.execute_range_dev(d_in, lo, n_res, n_total, ob, oe, d_out, stream=st)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- kernel-only time with HIP events on the launch stream (roofline) ------------------
+    # same launch geometry as the timed steps when world == 1 (range == whole block)
+    ms_kernel = plan.time_dev(d_in, n_res if world > 1 else n_blk, d_out, max(5, a.steps), stream=st)
+    n_kernel = n_res if world > 1 else n_blk
+    bytes_per_sample = 4.0 + 4.0 / D
+    achieved = bytes_per_sample * n_kernel / (ms_kernel * 1e-3) / 1e9
+
+    # ---- spot parity at full size: three slices (start, past 2^31 bytes, end) vs the oracle --
+    parity = None
+    if rank == 0:
+        worst = 0.0
+        out_n = oe - ob
+        for j0 in (0, out_n // 2 + 12345, out_n - 4096):
+            j0 = max(0, min(j0, out_n - 4096))
+            J = ob + j0                           # first output of the slice (stream index)
+            s_lo = max(lo, J * D - (T - 1))
+            s_hi = min(hi, (J + 4096) * D + 1)
+            blk = d_in[2 * (s_lo - lo): 2 * (s_hi - lo)].cpu().numpy()
+            y = O.fir_decimate(O.unpack_scale_i16(blk), D, taps, pre=J * D - s_lo)
+            want = O.polar_discriminator(y, 1.0 / (2.0 * np.pi))[:4096]
+            got = d_out[j0: j0 + want.size].cpu().numpy().astype(np.float64)
+            worst = max(worst, float(np.abs(got - want).max()))
+        parity = worst
+        assert worst <= 1e-5 * 0.5, f"full-size parity failed: {worst}"
+
+    gather_ms = None
+    if dist and not a.no_gather:
+        # final collection of the decimated output on rank 0 over xGMI (RCCL gather), once per job
+        m = max((cnt_total * (r + 1) // world) - (cnt_total * r // world) for r in range(world))
+        send = d_out[:m].contiguous()
+        recv = [torch.empty(m, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize(); dist.barrier()
+        g0 = time.perf_counter()
+        dist.gather(send, recv, dst=0)
+        torch.cuda.synchronize(); dist.barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        value = n_blk * world * a.steps / dt / 1e6
+        info = plan.info()
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("fir_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "input Msamples/s through FIR-decimate+FM demod",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"FM chain, single 20 MSps stream, 2^{a.log2n}-sample int16 IQ block per GPU, "
+                                   f"{T}-tap Hann LPF, decimate by {D}, discriminator (BASELINE configs[1])",
+                       "samples_per_gpu": n_blk, "taps": T, "decim": D,
+                       "sharding": "time blocks with FIR history halo" if world > 1 else "none",
+                       "kernel": info},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "kernel_ms": round(ms_kernel, 4),
+                         "algorithmic_bytes_per_sample": bytes_per_sample},
+            "parity_max_abs_err": parity,
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = round(gather_ms, 3)
+        if world == 1 and a.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(O, taps, D, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+/*
+ * sdr_hip.h -- C ABI of libsdrhip: the MI355X (gfx950) receive-side DSP hot path of
+ * davemers0160/SDR (int16 IQ -> FIR + decimate -> FM discriminator | envelope | IQ, NCO mix,
+ * windowed FFT -> dB).
+ *
+ * The reference has no FFI for this path: its boundary is a set of header-only C++ free
+ * functions over std::vector.  Each entry point below names the reference
+ * interface it replaces (file:line relative to the reference root).  include/sdr_hip_shims.hpp
+ * re-creates those C++ signatures on top of this ABI; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns an int status (SDR_OK == 0) except
+ *     the *_strerror / *_count helpers.  Where the reference throws std::invalid_argument
+ *     (bladerf_apt_demod.cpp:254-259) the ABI returns SDR_EINVAL.
+ *   - IQ input is interleaved little-endian int16 (I then Q, 4 B per sample, Q11), i.e. the
+ *     memory of std::vector<std::complex<int16_t>> / std::vector<int16_t> IQIQ...
+ *     (bladerf_sdr.h:273,281; bladerf_main_v1.cpp:128,175).  Complex float is interleaved
+ *     (re, im) float32 == std::complex<float>.
+ *   - *_host entry points take host pointers (they stage through device memory owned by the
+ *     plan); *_dev entry points take device pointers and a hipStream_t passed as void*
+ *     (NULL = the default stream) and only enqueue work.
+ *   - there is NO CPU fallback: without a gfx950 device sdr_init() and every plan call fail
+ *     with SDR_ENODEV.
+ */
+#ifndef SDR_HIP_H_
+#define SDR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum sdr_status {
+    SDR_OK = 0,
+    SDR_EINVAL = 1,     /* bad argument (the reference's std::invalid_argument) */
+    SDR_ENOMEM = 2,
+    SDR_EHIP = 3,       /* a HIP runtime call failed; see sdr_last_error() */
+    SDR_EALIGN = 4,     /* pointer not aligned to its sample type */
+    SDR_ECAPACITY = 5,  /* output buffer too small */
+    SDR_ENODEV = 6,     /* no gfx950 device */
+    SDR_ERANGE = 7      /* requested samples are outside the resident window */
+};
+
+/* output of the FIR-decimate chain */
+enum sdr_mode {
+    SDR_MODE_IQ = 0,    /* complex y[m] (float2)           -- polyphase_decimate alone        */
+    SDR_MODE_FM = 1,    /* scale*arg(y[m+1] conj(y[m]))    -- + polar_discriminator           */
+    SDR_MODE_ENV = 2    /* |y[m]|                          -- + std::abs envelope             */
+};
+
+/* sample type of the input stream */
+enum sdr_input {
+    SDR_IN_I16_IQ = 0,  /* interleaved int16 I,Q; the 1/2048 Q11 scale is applied            */
+    SDR_IN_CF32 = 1,    /* interleaved float32 re,im (already scaled)                         */
+    SDR_IN_F32_REAL = 2 /* float32 real (e.g. the discriminator output fed to APT stage 2)    */
+};
+
+enum sdr_window_id {
+    SDR_WIN_RECTANGULAR = 0, SDR_WIN_HANN = 1, SDR_WIN_HAMMING = 2, SDR_WIN_BLACKMAN = 3,
+    SDR_WIN_NUTTALL = 4, SDR_WIN_BLACKMAN_HARRIS = 5
+};
+
+typedef struct sdr_fir_plan sdr_fir_plan;
+typedef struct sdr_fft_plan sdr_fft_plan;
+
+/* ---- library ------------------------------------------------------------------------------ */
+
+/* Select `device` (HIP ordinal) for the calling thread and check that it is gfx950.
+ * No reference counterpart (the reference is CPU-only). */
+int sdr_init(int device);
+const char *sdr_strerror(int status);
+/* text of the last failure on the calling thread (HIP error string, argument name...) */
+const char *sdr_last_error(void);
+/* device memory helpers so that non-HIP hosts (ctypes, cgo...) can own device buffers */
+int sdr_dev_alloc(void **ptr, size_t bytes);
+int sdr_dev_free(void *ptr);
+int sdr_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int sdr_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+int sdr_dev_sync(void);
+
+/* ---- a11: filter design (host code, no kernel) ---------------------------------------------
+ * Replaces DSP::create_fir_filter<T>(n_taps, fc, &DSP::xxx_window) and DSP::xxx_window(N) of the
+ * un-vendored davemers0160/Common repo; call sites bladerf_fm_demod.cpp:215,229,232,
+ * bladerf_am_demod.cpp:217, bladerf_apt_demod.cpp:571,574.  PARITY UNPINNED (source absent):
+ * symmetric window w[n] over n/(N-1); h[n] = w[n]*sin(pi*fc*t)/(pi*t), t = n-(N-1)/2, h = fc*w
+ * at t = 0; no gain normalisation. */
+int sdr_window(int window_id, size_t n, double *w);
+int sdr_create_fir_filter(size_t n_taps, double fc, int window_id, double *h);
+
+/* ---- a2/a3/a4/a5/a6/a7: FIR + decimate (+ demod) plan -------------------------------------- */
+typedef struct sdr_fir_desc {
+    int input;          /* enum sdr_input */
+    int mode;           /* enum sdr_mode */
+    int decim;          /* D >= 1 */
+    int n_taps;         /* T >= 1; NO "T % D == 0" restriction */
+    const double *taps; /* host, T doubles (rounded to float32 on upload) */
+    double scale;       /* FM: discriminator scale, e.g. 1/(2*pi) (bladerf_apt_demod.cpp:560) */
+    double mix_fr;      /* != 0: multiply x[n] by exp(+j*2*pi*mix_fr*n) before the FIR
+                           (frequency_shift, bladerf_apt_demod.cpp:476-495; sign as
+                           create_freq_rotation, sdr_functions.h:63-74).  n is the index in the
+                           whole stream, so time-block shards stay phase-continuous. */
+    int outputs_per_lane; /* 0 = choose automatically; else 1, 2, 4 or 8 (tuning knob) */
+    int threads;          /* 0 = choose automatically; else 64, 128 or 256 */
+} sdr_fir_desc;
+
+/* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument
+ * checks + polyphase table) and af::array(lpf) (bladerf_fm_demod.cpp:217). */
+int sdr_fir_plan_create(const sdr_fir_desc *desc, sdr_fir_plan **plan);
+int sdr_fir_plan_destroy(sdr_fir_plan *plan);
+/* number of outputs for n_in input samples: floor(n_in/D) (bladerf_apt_demod.cpp:282), minus
+ * one in FM mode (:409). */
+size_t sdr_fir_out_count(const sdr_fir_plan *plan, size_t n_in);
+/* what the plan chose: outputs per lane, threads per workgroup, LDS bytes per workgroup */
+int sdr_fir_plan_info(const sdr_fir_plan *plan, int *outputs_per_lane, int *threads,
+                      int *lds_bytes);
+
+/* One block from zero pre-history, host buffers.  Replaces, fused in one pass,
+ *   the int16 -> float scale loop      bladerf_apt_demod.cpp:728-732 / bladerf_sdr.h:288-291
+ *   polyphase_decimate(x, D, h)        bladerf_apt_demod.cpp:249-313
+ *     (== af::fir + x3(dec_seq)        bladerf_fm_demod.cpp:291-294, bladerf_am_demod.cpp:294-297)
+ *   polar_discriminator(x4, scale)     bladerf_apt_demod.cpp:405-425   (SDR_MODE_FM)
+ *   std::abs / af::abs envelope        bladerf_apt_demod.cpp:750-754, bladerf_am_demod.cpp:311
+ * out: float (FM, ENV) or float2 (IQ); out_capacity in output elements. */
+int sdr_fir_execute_host(sdr_fir_plan *plan, const void *in, size_t n_in, void *out,
+                         size_t out_capacity, size_t *n_out);
+
+/* Same, device buffers, asynchronous on `stream`. */
+int sdr_fir_execute_dev(sdr_fir_plan *plan, const void *d_in, size_t n_in, void *d_out,
+                        size_t out_capacity, size_t *n_out, void *stream);
+
+/* Time-block sharding: the stream has n_total samples; d_in points at the sample
+ * with stream index in_first and n_resident samples are readable from it.  Computes the
+ * whole-stream outputs j in [out_begin, out_end) into d_out[0 .. out_end-out_begin).  The
+ * caller keeps the FIR history halo resident: samples D*out_begin-(T-1) .. D*(out_end-1)
+ * (one more output, i.e. up to D*out_end, in FM mode) clipped to [0, n_total); otherwise
+ * SDR_ERANGE.  No reference counterpart: the reference filters every block from zero state
+ * (bladerf_fm_demod.cpp:284-291). */
+int sdr_fir_execute_range_dev(sdr_fir_plan *plan, const void *d_in, uint64_t in_first,
+                              uint64_t n_resident, uint64_t n_total, uint64_t out_begin,
+                              uint64_t out_end, void *d_out, void *stream);
+
+/* Batched independent channels (BASELINE config 3): channel c reads n_in samples at
+ * d_in + c*in_stride samples and writes sdr_fir_out_count() outputs at d_out + c*out_stride
+ * output elements; every channel starts from zero pre-history.  One launch. */
+int sdr_fir_execute_batched_dev(sdr_fir_plan *plan, const void *d_in, size_t n_in,
+                                size_t in_stride, size_t n_channels, void *d_out,
+                                size_t out_stride, void *stream);
+
+/* ---- a10: windowed FFT -> power in dB ------------------------------------------------------
+ * Replaces bladerf_main_v1.cpp:183-196: complex<float>(I,Q)*(1/2048) -> af::fftInPlace(x, 1/N)
+ * -> 20*log10(shift(abs(X), N/2)); plus the window multiply and hop of BASELINE config 4.
+ * Frame f covers samples [f*hop, f*hop+nfft); out[f*nfft + i] = 10*log10(|X_f[(i+nfft/2) %
+ * nfft]|^2) with X = (1/nfft) * DFT(w .* x/2048).  No log floor (exact zeros give -inf, as in
+ * the reference).  nfft: a power of two, 64 .. 4096.  window may be NULL (rectangular). */
+int sdr_fft_plan_create(int nfft, int hop, const double *window, sdr_fft_plan **plan);
+int sdr_fft_plan_destroy(sdr_fft_plan *plan);
+size_t sdr_fft_frame_count(const sdr_fft_plan *plan, size_t n_in);
+int sdr_fft_execute_i16_host(sdr_fft_plan *plan, const int16_t *iq, size_t n_in, float *out_db,
+                             size_t frame_capacity, size_t *n_frames);
+int sdr_fft_execute_i16_dev(sdr_fft_plan *plan, const int16_t *d_iq, size_t n_in,
+                            float *d_out_db, size_t frame_capacity, size_t *n_frames,
+                            void *stream);
+
+/* ---- a6 (waterfall row): |x|/2048 straight from int16 --------------------------------------
+ * Replaces the std::transform at bladerf_waterfall_main.cpp:272. */
+int sdr_magnitude_i16_dev(const int16_t *d_iq, size_t n, float *d_mag, void *stream);
+
+/* ---- a2 alone: int16 -> complex float, x 1/2048 ---------------------------------------------
+ * Replaces the scale loop of bladerf_sdr.h:288-291,334-337 for callers that want the float
+ * stream itself. */
+int sdr_unpack_i16_dev(const int16_t *d_iq, size_t n, float *d_cf32, void *stream);
+
+/* ---- a7 alone: frequency shift / rotation vector --------------------------------------------
+ * frequency_shift (bladerf_apt_demod.cpp:476-495) on a real (is_complex = 0) or complex float
+ * stream: out[n] = in[n]*exp(+j*2*pi*fr*(n0+n)); with d_in == NULL it writes the rotation
+ * itself, i.e. create_freq_rotation (sdr_functions.h:63-74). */
+int sdr_frequency_shift_dev(const float *d_in, int is_complex, size_t n, uint64_t n0, double fr,
+                            float *d_out_cf32, void *stream);
+
+/* ---- synthetic input (test/bench support; no reference counterpart) --------------------------
+ * Writes n int16 IQ samples of an FM-modulated tone, stream indices n0 .. n0+n-1:
+ * phi = (dev/ftone)*sin(2*pi*ftone*t/fs), I = round(amp*cos phi), Q = round(amp*sin phi), plus
+ * uniform noise of +-noise_lsb.  Same law as the FM generators of the reference's TX examples
+ * (amplitude ~2000, bladerf/tx_example/src/bladerf_tx_main_v1.cpp:120-138) and SURVEY 8d. */
+int sdr_synth_fm_i16_dev(int16_t *d_iq, size_t n, uint64_t n0, double fs, double ftone,
+                         double dev, double amp, int noise_lsb, unsigned seed, void *stream);
+
+/* ---- timing helper for roofline measurement -------------------------------------------------
+ * Enqueues `iters` back-to-back launches of the plan's kernel bracketed by HIP events on
+ * `stream` and returns the average milliseconds per launch (synchronises). */
+int sdr_fir_time_dev(sdr_fir_plan *plan, const void *d_in, size_t n_in, size_t in_stride,
+                     size_t n_channels, void *d_out, size_t out_stride, int iters, void *stream,
+                     float *ms_per_launch);
+int sdr_fft_time_dev(sdr_fft_plan *plan, const int16_t *d_iq, size_t n_in, float *d_out_db,
+                     int iters, void *stream, float *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDR_HIP_H_ */

@@ -1,0 +1,309 @@
+"""ctypes binding of libsdrhip.so (include/sdr_hip.h).
+
+This is the Python host side used by the tests and bench.py.  It is plumbing only: every
+compute call goes through the C ABI into the HIP kernels.  There is no CPU fallback -- if the
+shared library is missing, or no gfx950 device is present, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdrhip.so")
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "lib.hip")]
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+OK, EINVAL, ENOMEM, EHIP, EALIGN, ECAPACITY, ENODEV, ERANGE = range(8)
+MODE_IQ, MODE_FM, MODE_ENV = 0, 1, 2
+IN_I16_IQ, IN_CF32, IN_F32_REAL = 0, 1, 2
+WINDOWS = {"rectangular": 0, "hann": 1, "hamming": 2, "blackman": 3, "nuttall": 4,
+           "blackman_harris": 5}
+
+
+class SdrError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"libsdrhip status {status}: {msg}")
+        self.status = status
+
+
+class FirDesc(C.Structure):
+    _fields_ = [("input", C.c_int), ("mode", C.c_int), ("decim", C.c_int), ("n_taps", C.c_int),
+                ("taps", C.POINTER(C.c_double)), ("scale", C.c_double), ("mix_fr", C.c_double),
+                ("outputs_per_lane", C.c_int), ("threads", C.c_int)]
+
+
+def build(force=False):
+    """hipcc -> sdr_amd/libsdrhip.so (cross-compiles for gfx950 without a GPU)."""
+    srcs = [s for s in SOURCES if os.path.exists(s)]
+    deps = srcs + [os.path.join(_HERE, "csrc", "sdr_internal.h"),
+                   os.path.join(INCLUDE, "sdr_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and \
+            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + INCLUDE, "-I" + os.path.join(_HERE, "csrc"), "-o", LIB_PATH] + srcs
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdrError(ENODEV, f"{LIB_PATH} not built (run __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.sdr_strerror.restype = C.c_char_p
+        L.sdr_last_error.restype = C.c_char_p
+        L.sdr_fir_out_count.restype = C.c_size_t
+        L.sdr_fir_out_count.argtypes = [C.c_void_p, C.c_size_t]
+        L.sdr_fft_frame_count.restype = C.c_size_t
+        L.sdr_fft_frame_count.argtypes = [C.c_void_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        L = lib()
+        raise SdrError(status, f"{L.sdr_strerror(status).decode()} -- {L.sdr_last_error().decode()}")
+
+
+def init(device=0):
+    check(lib().sdr_init(C.c_int(device)))
+
+
+# ------------------------------------------------------------------------------ host design --
+def window(name, n):
+    w = np.zeros(n, np.float64)
+    check(lib().sdr_window(C.c_int(WINDOWS[name]), C.c_size_t(n),
+                           w.ctypes.data_as(C.POINTER(C.c_double))))
+    return w
+
+
+def create_fir_filter(n_taps, fc, window_name="hann"):
+    h = np.zeros(n_taps, np.float64)
+    check(lib().sdr_create_fir_filter(C.c_size_t(n_taps), C.c_double(fc),
+                                      C.c_int(WINDOWS[window_name]),
+                                      h.ctypes.data_as(C.POINTER(C.c_double))))
+    return h
+
+
+# ---------------------------------------------------------------------------- device memory --
+class DevBuf:
+    """A device allocation owned through the C ABI (sdr_dev_alloc / sdr_dev_free)."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        check(lib().sdr_dev_alloc(C.byref(self.ptr), C.c_size_t(self.nbytes)))
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        check(lib().sdr_dev_upload(b.ptr, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)))
+        return b
+
+    def to_numpy(self, dtype, count, offset_bytes=0):
+        out = np.empty(count, dtype)
+        check(lib().sdr_dev_download(out.ctypes.data_as(C.c_void_p),
+                                     C.c_void_p(self.ptr.value + offset_bytes),
+                                     C.c_size_t(out.nbytes)))
+        return out
+
+    def at(self, offset_bytes):
+        return C.c_void_p(self.ptr.value + int(offset_bytes))
+
+    def free(self):
+        if self.ptr and self.ptr.value:
+            lib().sdr_dev_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync():
+    check(lib().sdr_dev_sync())
+
+
+def _vp(x):
+    """device pointer argument: DevBuf, c_void_p, int, or a torch CUDA tensor"""
+    if isinstance(x, DevBuf):
+        return x.ptr
+    if isinstance(x, C.c_void_p):
+        return x
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(type(x))
+
+
+# ---------------------------------------------------------------------------------- FIR plan --
+class FirPlan:
+    """sdr_fir_plan: FIR + decimate (+ mixer) + {IQ, FM discriminator, envelope}."""
+
+    def __init__(self, taps, decim, mode=MODE_FM, input=IN_I16_IQ, scale=1.0 / (2.0 * np.pi),
+                 mix_fr=0.0, outputs_per_lane=0, threads=0):
+        self._taps = np.ascontiguousarray(taps, dtype=np.float64)
+        self.mode, self.input, self.decim = mode, input, decim
+        d = FirDesc(input, mode, decim, self._taps.size,
+                    self._taps.ctypes.data_as(C.POINTER(C.c_double)), scale, mix_fr,
+                    outputs_per_lane, threads)
+        self.h = C.c_void_p()
+        check(lib().sdr_fir_plan_create(C.byref(d), C.byref(self.h)))
+
+    def info(self):
+        r, nt, lds = C.c_int(), C.c_int(), C.c_int()
+        check(lib().sdr_fir_plan_info(self.h, C.byref(r), C.byref(nt), C.byref(lds)))
+        return {"outputs_per_lane": r.value, "threads": nt.value, "lds_bytes": lds.value}
+
+    def out_count(self, n_in):
+        return lib().sdr_fir_out_count(self.h, n_in)
+
+    @property
+    def out_dtype(self):
+        return np.complex64 if self.mode == MODE_IQ else np.float32
+
+    def _in_array(self, x):
+        if self.input == IN_I16_IQ:
+            a = np.ascontiguousarray(x, dtype=np.int16).reshape(-1)
+            return a, a.size // 2
+        if self.input == IN_CF32:
+            a = np.ascontiguousarray(x, dtype=np.complex64).reshape(-1)
+            return a, a.size
+        a = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        return a, a.size
+
+    def execute_host(self, x):
+        a, n = self._in_array(x)
+        cnt = self.out_count(n)
+        out = np.empty(max(cnt, 1), self.out_dtype)
+        n_out = C.c_size_t()
+        check(lib().sdr_fir_execute_host(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                         out.ctypes.data_as(C.c_void_p), C.c_size_t(cnt),
+                                         C.byref(n_out)))
+        return out[: n_out.value]
+
+    def execute_dev(self, d_in, n_in, d_out, out_capacity, stream=None):
+        n_out = C.c_size_t()
+        check(lib().sdr_fir_execute_dev(self.h, _vp(d_in), C.c_size_t(n_in), _vp(d_out),
+                                        C.c_size_t(out_capacity), C.byref(n_out),
+                                        C.c_void_p(stream or 0)))
+        return n_out.value
+
+    def execute_range_dev(self, d_in, in_first, n_resident, n_total, out_begin, out_end, d_out,
+                          stream=None):
+        check(lib().sdr_fir_execute_range_dev(self.h, _vp(d_in), C.c_uint64(in_first),
+                                              C.c_uint64(n_resident), C.c_uint64(n_total),
+                                              C.c_uint64(out_begin), C.c_uint64(out_end),
+                                              _vp(d_out), C.c_void_p(stream or 0)))
+
+    def execute_batched_dev(self, d_in, n_in, in_stride, n_channels, d_out, out_stride,
+                            stream=None):
+        check(lib().sdr_fir_execute_batched_dev(self.h, _vp(d_in), C.c_size_t(n_in),
+                                                C.c_size_t(in_stride), C.c_size_t(n_channels),
+                                                _vp(d_out), C.c_size_t(out_stride),
+                                                C.c_void_p(stream or 0)))
+
+    def time_dev(self, d_in, n_in, d_out, iters, in_stride=0, n_channels=1, out_stride=0,
+                 stream=None):
+        """average ms per kernel launch, measured with HIP events on the launch stream"""
+        ms = C.c_float()
+        check(lib().sdr_fir_time_dev(self.h, _vp(d_in), C.c_size_t(n_in), C.c_size_t(in_stride),
+                                     C.c_size_t(n_channels), _vp(d_out), C.c_size_t(out_stride),
+                                     C.c_int(iters), C.c_void_p(stream or 0), C.byref(ms)))
+        return ms.value
+
+    def destroy(self):
+        if self.h and self.h.value:
+            lib().sdr_fir_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------- FFT plan --
+class FftPlan:
+    def __init__(self, nfft, hop, window=None):
+        self.nfft, self.hop = nfft, hop
+        w = None if window is None else np.ascontiguousarray(window, dtype=np.float64)
+        self.h = C.c_void_p()
+        check(lib().sdr_fft_plan_create(C.c_int(nfft), C.c_int(hop),
+                                        w.ctypes.data_as(C.POINTER(C.c_double)) if w is not None
+                                        else None, C.byref(self.h)))
+
+    def frame_count(self, n_in):
+        return lib().sdr_fft_frame_count(self.h, n_in)
+
+    def execute_host(self, iq):
+        a = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1)
+        n = a.size // 2
+        frames = self.frame_count(n)
+        out = np.empty((max(frames, 1), self.nfft), np.float32)
+        nf = C.c_size_t()
+        check(lib().sdr_fft_execute_i16_host(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                             out.ctypes.data_as(C.c_void_p), C.c_size_t(frames),
+                                             C.byref(nf)))
+        return out[: nf.value]
+
+    def execute_dev(self, d_iq, n_in, d_out, frame_capacity, stream=None):
+        nf = C.c_size_t()
+        check(lib().sdr_fft_execute_i16_dev(self.h, _vp(d_iq), C.c_size_t(n_in), _vp(d_out),
+                                            C.c_size_t(frame_capacity), C.byref(nf),
+                                            C.c_void_p(stream or 0)))
+        return nf.value
+
+    def time_dev(self, d_iq, n_in, d_out, iters, stream=None):
+        ms = C.c_float()
+        check(lib().sdr_fft_time_dev(self.h, _vp(d_iq), C.c_size_t(n_in), _vp(d_out),
+                                     C.c_int(iters), C.c_void_p(stream or 0), C.byref(ms)))
+        return ms.value
+
+    def destroy(self):
+        if self.h and self.h.value:
+            lib().sdr_fft_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------ element-wise calls --
+def unpack_i16_dev(d_iq, n, d_out, stream=None):
+    check(lib().sdr_unpack_i16_dev(_vp(d_iq), C.c_size_t(n), _vp(d_out), C.c_void_p(stream or 0)))
+
+
+def magnitude_i16_dev(d_iq, n, d_out, stream=None):
+    check(lib().sdr_magnitude_i16_dev(_vp(d_iq), C.c_size_t(n), _vp(d_out),
+                                      C.c_void_p(stream or 0)))
+
+
+def frequency_shift_dev(d_in, is_complex, n, n0, fr, d_out, stream=None):
+    check(lib().sdr_frequency_shift_dev(_vp(d_in) if d_in is not None else None,
+                                        C.c_int(1 if is_complex else 0), C.c_size_t(n),
+                                        C.c_uint64(n0), C.c_double(fr), _vp(d_out),
+                                        C.c_void_p(stream or 0)))
+
+
+def synth_fm_i16_dev(d_iq, n, n0=0, fs=1.0e6, ftone=1000.0, dev=5000.0, amp=2000.0, noise_lsb=0,
+                     seed=1, stream=None):
+    check(lib().sdr_synth_fm_i16_dev(_vp(d_iq), C.c_size_t(n), C.c_uint64(n0), C.c_double(fs),
+                                     C.c_double(ftone), C.c_double(dev), C.c_double(amp),
+                                     C.c_int(noise_lsb), C.c_uint(seed), C.c_void_p(stream or 0)))

@@ -1,0 +1,30 @@
+// Internal helpers shared by the libsdrhip translation units (not part of the ABI).
+#ifndef SDR_INTERNAL_H_
+#define SDR_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "sdr_hip.h"
+
+namespace sdr {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+bool device_ready();          // true once the current device has been verified to be gfx950
+int ensure_device();          // SDR_OK or SDR_ENODEV / SDR_EHIP
+
+#define SDR_HIP(call)                                         \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return ::sdr::hip_fail(e_, #call); \
+    } while (0)
+
+// 2^-11: the Q11 scale of BLADERF_FORMAT_SC16_Q11 samples (bladerf_sdr.h:274)
+constexpr float kQ11 = 1.0f / 2048.0f;
+
+}  // namespace sdr
+
+#endif

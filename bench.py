@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--outputs-per-lane", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--no-gather", action="store_true")
     return ap.parse_args()
 
@@ -96,7 +97,8 @@ def main():
     n_total = n_blk * world
     taps = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")     # cutoff at the decimated Nyquist
     plan = sdr_amd.FirPlan(taps, D, mode=sdr_amd.MODE_FM, scale=1.0 / (2.0 * np.pi),
-                           outputs_per_lane=a.outputs_per_lane, threads=a.threads)
+                           outputs_per_lane=a.outputs_per_lane, threads=a.threads,
+                           pipeline=a.pipeline)
     cnt_total = plan.out_count(n_total)
     ob = cnt_total * rank // world             # this rank's slice of the final output
     oe = cnt_total * (rank + 1) // world

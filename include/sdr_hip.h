@@ -103,6 +103,10 @@ typedef struct sdr_fir_desc {
                            whole stream, so time-block shards stay phase-continuous. */
     int outputs_per_lane; /* 0 = choose automatically; else 1, 2, 4 or 8 (tuning knob) */
     int threads;          /* 0 = choose automatically; else 64, 128 or 256 */
+    int pipeline;         /* kernel choice: 0 = automatic; 1 = raw int16 tiles in LDS filled by
+                             LDS-DMA, one tile per workgroup (int16 input without mixer only);
+                             2 = float tiles converted once, persistent workgroups that prefetch
+                             the next tile into registers (any input) */
 } sdr_fir_desc;
 
 /* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument
@@ -115,6 +119,8 @@ size_t sdr_fir_out_count(const sdr_fir_plan *plan, size_t n_in);
 /* what the plan chose: outputs per lane, threads per workgroup, LDS bytes per workgroup */
 int sdr_fir_plan_info(const sdr_fir_plan *plan, int *outputs_per_lane, int *threads,
                       int *lds_bytes);
+/* which kernel the plan runs: 1 = raw-tile kernel, 2 = streaming kernel (see `pipeline`) */
+int sdr_fir_plan_kernel(const sdr_fir_plan *plan);
 
 /* One block from zero pre-history, host buffers.  Replaces, fused in one pass,
  *   the int16 -> float scale loop      bladerf_apt_demod.cpp:728-732 / bladerf_sdr.h:288-291

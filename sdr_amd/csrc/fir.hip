@@ -9,24 +9,31 @@
 //   std::abs envelope             bladerf_apt_demod.cpp:750-754
 //
 // Work assignment ("output stride"): a workgroup of NT lanes owns a tile of NT*R consecutive
-// outputs; lane l owns outputs m0 = M0 + l*R .. m0+R-1.  The input window of the tile
-//   samples W0 = D*M0 - Tback  ..  D*(M0+NT*R) + 1      (Tback = (T-1) rounded up to 4)
+// outputs; lane l owns outputs m0 = M0 + l*R .. m0+R-1.  The input window of the tile,
+//   samples W0 = D*M0 - Tback  ..  D*(M0+NT*R) + 1        (Tback = (T-1) rounded up to 4),
 // i.e. the tile's own D*NT*R samples plus the overlap-save halo of T-1 history samples (and D
-// more on the right for the discriminator's successor), is staged once in LDS:
-//   * int16 IQ without mixer: the raw 4-byte samples are copied HBM -> LDS by LDS-DMA
-//     (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip) and converted
-//     after the LDS read (the 2^-11 scale is folded into the taps, exact);
-//   * every other input (complex float, real float, any input with the NCO mixer on) is
-//     converted / mixed once while staging and kept as float2.
-// Lane l then walks its window [D*R*l, D*R*l + Lw) with 16-byte LDS reads.  One loaded sample
-// feeds all R outputs of the lane: output r uses tap D*r + Tback - j for window offset j, which
-// the host has laid out as a zero-padded table gtab[j][r]; the table index is wave-uniform, so
-// taps arrive through scalar loads and cost no LDS or VALU work.  Lane stride in LDS is
-// q = D*R/(samples per 16 B) granules; when q is even the tile is stored with one pad granule
-// per q (stride q+1, odd) so that the 16-lane groups of ds_read_b128 hit distinct banks.
+// more on the right for the discriminator's successor), is staged once in LDS and every lane
+// walks its own window [D*R*l, D*R*l + Lw) with 16-byte LDS reads.  One loaded sample feeds all
+// R outputs of the lane: output r uses tap D*r + Tback - j at window offset j, which the host
+// lays out as a zero-padded table gtab[j][r]; the table index is wave-uniform, so taps arrive
+// through scalar loads and cost no LDS or VALU work.
 //
-// Numerics: float32 fmaf accumulation in ascending window order; decimation indexing is exact
-// (output m <-> input D*m); zero pre-history (samples < 0 read as 0) as the reference.
+// Two kernels share that scheme:
+//   fir_stream_kernel  (the default) keeps FLOAT samples in LDS: persistent workgroups fetch the
+//       raw tile k+1 from HBM into registers while they walk tile k, then convert it ONCE per
+//       sample (int16 -> f32 is a half-rate VALU op on gfx950, and a sample is read by ~4 lanes),
+//       apply the optional NCO mixer, and write float2 to LDS.  Any input type.
+//   fir_raw_kernel     keeps the RAW int16 pairs in LDS, filled by LDS-DMA
+//       (global_load_lds_dwordx4, no VGPR round trip), and converts after each LDS read.  Half
+//       the LDS footprint; kept for shapes whose float tile does not fit (plan `pipeline` = 1).
+// Lane stride in LDS is q = D*R/(samples per 16 B) granules; when q is even the tile image
+// carries one pad granule per q (stride q+1, odd) so that ds_read_b128's 16-lane groups hit
+// distinct banks.
+//
+// Numerics: float32 fmaf accumulation in ascending window order (identical for every tile
+// placement); decimation indexing is exact (output m <-> input D*m); zero pre-history (samples
+// < 0 read as 0) as the reference.  For int16 input the exact 2^-11 Q11 scale is folded into the
+// taps.
 
 #include <cmath>
 #include <cstring>
@@ -48,24 +55,26 @@ struct FirGeom {
     int D;
     int T;
     int Tback;              // roundup4(T-1)
-    int ngran;              // 16-byte granules in one lane's window
+    int ngran;              // 16-byte granules in one lane's (padded) window
     int q;                  // lane stride in sample granules
     int pad;                // 1: one pad granule after every q sample granules
-    unsigned magic;         // ceil(2^32/(q+1)) for the staging division
+    unsigned magic;         // ceil(2^32/(q+1)): staging division
+    unsigned magic_q;       // ceil(2^32/q): walker pad offset
     int s_gran;             // sample granules staged per tile
     int a_gran;             // LDS granules per tile (pads included, rounded up to NT)
+    int n_inst;             // a_gran / NT
     int mode;               // sdr_mode
-    int input;              // sdr_input
     float scale;            // discriminator scale
+    int tiles_per_ch;
+    int total_tiles;
 };
 
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+enum { IN_I16 = SDR_IN_I16_IQ, IN_CF32 = SDR_IN_CF32, IN_REAL = SDR_IN_F32_REAL };
 
+// LDS granule that holds sample granule sg
 __device__ __forceinline__ int lds_granule(const FirGeom &g, int sg)
 {
-    // LDS granule that holds sample granule sg
-    return g.pad ? sg + sg / g.q : sg;
+    return g.pad ? sg + (int)__umulhi((unsigned)sg, g.magic_q) : sg;
 }
 
 // sample granule held by LDS granule a (pad granules duplicate their left neighbour)
@@ -87,15 +96,48 @@ __device__ __forceinline__ float2 wave_sum(float2 v)
     return v;
 }
 
+__device__ __forceinline__ float lo16(uint32_t w) { return (float)(short)(w & 0xffffu); }
+__device__ __forceinline__ float hi16(uint32_t w) { return (float)((int)w >> 16); }
+
 // polar_discriminator, bladerf_apt_demod.cpp:419-421: tmp = y1 * conj(y0); scale*atan2(im, re).
 // Written as libstdc++ evaluates the product, (a*c - b*e, a*e + b*c) with e = -d, so that a
 // zero y0 produces the same signed zeros (and therefore the same 0 / +-pi) as the reference.
+// atan2 for finite arguments, ~3 ulp (|err| < 7e-7 rad, i.e. 1.1e-7 of a turn), signed zeros as
+// IEEE atan2 (atan2(+-0, -0) = +-pi, atan2(+-0, +0) = +-0).  About a third of the instructions of
+// the library call, which matters because the walk leaves the kernel VALU-bound.
+// Reduction to [0, 1] by swapping, one Newton step on v_rcp_f32, odd minimax polynomial.
+__device__ __forceinline__ float atan2_finite(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float sc = (mx < 1e-30f) ? 1.8446744e19f : 1.0f;     // keep v_rcp_f32 out of the denormals
+    mx *= sc;
+    mn *= sc;
+    const float r = __builtin_amdgcn_rcpf(mx);
+    float s = mn * r;
+    s = __fmaf_rn(__fmaf_rn(-mx, s, mn), r, s);           // refine mn/mx
+    s = (mx == 0.0f) ? 0.0f : s;
+    const float t = s * s;
+    float u = 0.00282363896258175373077393f;
+    u = __fmaf_rn(u, t, -0.0159569028764963150024414f);
+    u = __fmaf_rn(u, t, 0.0425049886107444763183594f);
+    u = __fmaf_rn(u, t, -0.0748900920152664184570312f);
+    u = __fmaf_rn(u, t, 0.106347933411598205566406f);
+    u = __fmaf_rn(u, t, -0.142027363181114196777344f);
+    u = __fmaf_rn(u, t, 0.199926957488059997558594f);
+    u = __fmaf_rn(u, t, -0.333331018686294555664062f);
+    float a = __fmaf_rn(s * t, u, s);                     // atan(mn/mx) in [0, pi/4]
+    a = (ay > ax) ? 1.57079632679489661923f - a : a;
+    a = (__float_as_uint(x) >> 31) ? 3.14159265358979323846f - a : a;
+    return __uint_as_float(__float_as_uint(a) | (__float_as_uint(y) & 0x80000000u));
+}
+
 __device__ __forceinline__ float discriminate(float2 y1, float2 y0, float scale)
 {
     const float a = y1.x, b = y1.y, c = y0.x, e = -y0.y;
     const float re = __fmaf_rn(a, c, -(b * e));
     const float im = __fmaf_rn(a, e, b * c);
-    return scale * atan2f(im, re);
+    return scale * atan2_finite(im, re);
 }
 
 template <int R>
@@ -118,7 +160,9 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
         for (int r = 0; r < R; ++r) v[r] = discriminate(r + 1 < R ? y[r + 1] : ynext, y[r], g.scale);
     } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = hypotf(y[r].x, y[r].y);
+        // std::abs(complex): |y| <= 16*sum|h| here, so the plain form cannot overflow; a result
+        // below 1e-19 (underflow of the squares) is 0 instead of tiny -- far under the tolerance
+        for (int r = 0; r < R; ++r) v[r] = sqrtf(__fmaf_rn(y[r].x, y[r].x, y[r].y * y[r].y));
     }
     float *out = (float *)outv + ch * g.out_stride;
     float *dst = out + (m0 - g.out_begin);
@@ -141,8 +185,329 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// int16 IQ, no mixer: raw samples in LDS (4 B each, 4 per granule), LDS-DMA staging.
+// The lane window walk, software-pipelined in source.  The window is consumed in steps of U
+// granules; the LDS data and the taps (scalar loads) of step k+1 are requested before the FMAs of
+// step k, from two register sets used alternately.  walk_touch() "uses" a set without doing
+// anything, which makes hipcc place its s_waitcnt for that set BEFORE the next set is requested
+// (scalar loads return out of order, so any later wait would be lgkmcnt(0) and would also wait
+// for the set that has only just been requested).  Host side pads the window to an even number
+// of steps plus one look-ahead step (zero taps), so the loop needs no bounds test.
+//   SPG = samples per 16-byte granule: 4 (raw int16 pairs) or 2 (float2).
 // ---------------------------------------------------------------------------------------------
+template <int SPG, int R> struct Walk {
+    // taps per step N = SPG*R*U = 16 (32 for R = 8)
+    static constexpr int U = (SPG * R >= 16) ? 1 : 16 / (SPG * R);
+    static constexpr int N = SPG * R * U;
+};
+
+template <bool PAD>
+__device__ __forceinline__ int walk_index(int c, const FirGeom &g)
+{
+    return PAD ? c + (int)__umulhi((unsigned)c, g.magic_q) : c;      // scalar: c is wave-uniform
+}
+
+template <int U, bool PAD>
+__device__ __forceinline__ void walk_load(uint4 (&v)[U], const uint4 *lane_base, int c,
+                                          const FirGeom &g)
+{
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = lane_base[walk_index<PAD>(c + k, g)];
+}
+
+template <int N>
+__device__ __forceinline__ void walk_taps(float (&t)[N], const float *__restrict__ gt)
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) t[k] = gt[k];
+}
+
+template <int U, int N>
+__device__ __forceinline__ void walk_touch(const uint4 (&v)[U], const float (&t)[N])
+{
+#pragma unroll
+    for (int k = 0; k < U; ++k) asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(v[k].z), "v"(v[k].w));
+#pragma unroll
+    for (int k = 0; k < N; k += 8)
+        asm volatile("" ::"s"(t[k]), "s"(t[k + 1]), "s"(t[k + 2]), "s"(t[k + 3]), "s"(t[k + 4]),
+                     "s"(t[k + 5]), "s"(t[k + 6]), "s"(t[k + 7]));
+}
+
+template <int SPG, int R, int U>
+__device__ __forceinline__ void walk_fma(const uint4 (&v)[U], const float (&t)[SPG * R * U],
+                                         float2 (&acc)[R])
+{
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        float xi[SPG], xq[SPG];
+        if (SPG == 4) {
+            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { xi[u] = lo16(w[u]); xq[u] = hi16(w[u]); }
+        } else {
+            xi[0] = __uint_as_float(v[k].x); xq[0] = __uint_as_float(v[k].y);
+            xi[1] = __uint_as_float(v[k].z); xq[1] = __uint_as_float(v[k].w);
+        }
+#pragma unroll
+        for (int u = 0; u < SPG; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float h = t[(k * SPG + u) * R + r];
+                acc[r].x = __fmaf_rn(h, xi[u], acc[r].x);
+                acc[r].y = __fmaf_rn(h, xq[u], acc[r].y);
+            }
+    }
+}
+
+template <int SPG, int R, bool PAD>
+__device__ __forceinline__ void walk_p(const FirGeom &g, const uint4 *lds4,
+                                       const float *__restrict__ gtab, int tid, float2 (&acc)[R])
+{
+    constexpr int U = Walk<SPG, R>::U;
+    constexpr int N = Walk<SPG, R>::N;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
+    const uint4 *lane_base = lds4 + tid * (g.q + (PAD ? 1 : 0));
+    const int nstep = g.ngran / U;           // even (host pads)
+    uint4 va[U], vb[U];
+    float ta[N], tb[N];
+    walk_load<U, PAD>(va, lane_base, 0, g);
+    walk_taps<N>(ta, gtab);
+    for (int s = 0; s < nstep; s += 2) {
+        walk_touch<U, N>(va, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        walk_load<U, PAD>(vb, lane_base, (s + 1) * U, g);
+        walk_taps<N>(tb, gtab + (size_t)(s + 1) * N);
+        __builtin_amdgcn_sched_barrier(0);
+        walk_fma<SPG, R, U>(va, ta, acc);
+        walk_touch<U, N>(vb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        walk_load<U, PAD>(va, lane_base, (s + 2) * U, g);      // look-ahead step (zero taps at the end)
+        walk_taps<N>(ta, gtab + (size_t)(s + 2) * N);
+        __builtin_amdgcn_sched_barrier(0);
+        walk_fma<SPG, R, U>(vb, tb, acc);
+    }
+}
+
+template <int SPG, int R>
+__device__ __forceinline__ void walk(const FirGeom &g, const uint4 *lds4,
+                                     const float *__restrict__ gtab, int tid, float2 (&acc)[R])
+{
+    if (g.pad) walk_p<SPG, R, true>(g, lds4, gtab, tid, acc);
+    else walk_p<SPG, R, false>(g, lds4, gtab, tid, acc);
+}
+
+// Successor of the tile's last output, y[M0 + NT*R], for the discriminator: the T taps are spread
+// over wave 0's lanes and summed across the wave.
+template <int SPG>
+__device__ __forceinline__ float2 successor_output(const FirGeom &g, const unsigned char *tile,
+                                                   const float *taps, int tid, int NT, int R)
+{
+    float2 part = make_float2(0.f, 0.f);
+    const int sbase = g.D * NT * R + g.Tback;          // window offset of sample D*(M0+NT*R)
+    for (int i = tid; i < g.T; i += 64) {
+        const int sidx = sbase - i;
+        const float h = taps[i];
+        float xi, xq;
+        if (SPG == 4) {
+            const uint32_t wv = ((const uint32_t *)tile)[lds_granule(g, sidx >> 2) * 4 + (sidx & 3)];
+            xi = lo16(wv); xq = hi16(wv);
+        } else {
+            const float2 x = ((const float2 *)tile)[lds_granule(g, sidx >> 1) * 2 + (sidx & 1)];
+            xi = x.x; xq = x.y;
+        }
+        part.x = __fmaf_rn(h, xi, part.x);
+        part.y = __fmaf_rn(h, xq, part.y);
+    }
+    return wave_sum(part);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fir_stream_kernel: float2 tiles, convert once, persistent workgroups with register prefetch.
+// LDS: [tile (a_gran float4) | ybuf (NT+2 float2) | taps (T float)].
+// ---------------------------------------------------------------------------------------------
+template <int IN> struct RawPair;                        // two consecutive input samples
+template <> struct RawPair<IN_I16> { typedef uint2 type; };
+template <> struct RawPair<IN_CF32> { typedef float4 type; };
+template <> struct RawPair<IN_REAL> { typedef float2 type; };
+
+// bytes of one RawPair
+template <int IN> struct PairBytes { static constexpr unsigned value = (IN == IN_CF32) ? 16u : 8u; };
+
+// Slow path for tiles that touch the ends of the valid window or a misaligned stream: every
+// sample predicated on its own.
+template <int IN>
+__device__ __forceinline__ typename RawPair<IN>::type
+fetch_pair_checked(const FirGeom &g, const void *__restrict__ src, long long s)
+{
+    typedef typename RawPair<IN>::type P;
+    const bool v0 = (s >= g.lo_valid && s < g.hi_valid);
+    const bool v1 = (s + 1 >= g.lo_valid && s + 1 < g.hi_valid);
+    P p;
+    if (IN == IN_CF32) {
+        const float2 a = v0 ? ((const float2 *)src)[s] : make_float2(0.f, 0.f);
+        const float2 b = v1 ? ((const float2 *)src)[s + 1] : make_float2(0.f, 0.f);
+        float4 r = make_float4(a.x, a.y, b.x, b.y);
+        memcpy(&p, &r, sizeof(p));
+    } else {
+        const uint32_t a = v0 ? ((const uint32_t *)src)[s] : 0u;
+        const uint32_t b = v1 ? ((const uint32_t *)src)[s + 1] : 0u;
+        uint2 r = make_uint2(a, b);
+        memcpy(&p, &r, sizeof(p));
+    }
+    return p;
+}
+
+__device__ __forceinline__ float2 mix(float2 x, double fr, long long s)
+{
+    // exp(+j*2*pi*fr*s): the phase in revolutions is reduced in double, so it is exact to
+    // ~1e-16*s*fr before the float sincospi
+    const double ph = fr * (double)s;
+    const float f = (float)(ph - rint(ph));
+    float sn, cs;
+    sincospif(2.0f * f, &sn, &cs);
+    return make_float2(__fmaf_rn(x.x, cs, -(x.y * sn)), __fmaf_rn(x.x, sn, x.y * cs));
+}
+
+template <int IN>
+__device__ __forceinline__ float4 convert_pair(const typename RawPair<IN>::type &p, double fr,
+                                               long long s)
+{
+    float2 x0, x1;
+    if (IN == IN_I16) {
+        uint2 w; memcpy(&w, &p, sizeof(w));
+        x0 = make_float2(lo16(w.x), hi16(w.x));
+        x1 = make_float2(lo16(w.y), hi16(w.y));
+    } else if (IN == IN_CF32) {
+        float4 w; memcpy(&w, &p, sizeof(w));
+        x0 = make_float2(w.x, w.y);
+        x1 = make_float2(w.z, w.w);
+    } else {
+        float2 w; memcpy(&w, &p, sizeof(w));
+        x0 = make_float2(w.x, 0.f);
+        x1 = make_float2(w.y, 0.f);
+    }
+    if (fr != 0.0) { x0 = mix(x0, fr, s); x1 = mix(x1, fr, s + 1); }
+    return make_float4(x0.x, x0.y, x1.x, x1.y);
+}
+
+struct TileRef { long long ch, M0, W0; const void *src; const unsigned char *wbase; bool fast; };
+
+template <int IN>
+__device__ __forceinline__ TileRef tile_ref(const FirGeom &g, const void *__restrict__ in, int t,
+                                            int per_tile)
+{
+    TileRef r;
+    const int ch = t / g.tiles_per_ch, tile = t - ch * g.tiles_per_ch;
+    r.ch = ch;
+    r.M0 = g.tile0 + (long long)tile * per_tile;
+    r.W0 = r.M0 * g.D - g.Tback;
+    const size_t esz = IN == IN_CF32 ? 8 : 4;
+    r.src = (const unsigned char *)in + (size_t)((long long)ch * g.in_stride) * esz;
+    r.wbase = (const unsigned char *)r.src + (size_t)r.W0 * esz;          // sample W0
+    // fast path: the whole staged window is valid and pairs are naturally aligned
+    r.fast = (r.W0 >= g.lo_valid) && (r.W0 + 2LL * g.s_gran <= g.hi_valid) &&
+             ((((uintptr_t)r.src) & (IN == IN_CF32 ? 15 : 7)) == 0);
+    return r;
+}
+
+constexpr int kSlotsSmall = 12, kSlots = 32;   // 2-sample granules one lane stages per tile
+
+template <int IN, int R, int SLOTS>
+__global__ void __launch_bounds__(256, (SLOTS <= kSlotsSmall ? 3 : 2))
+fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
+                  const float *__restrict__ gtab, const float *__restrict__ taps, const FirGeom g)
+{
+    typedef typename RawPair<IN>::type P;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int NT = blockDim.x;
+    float4 *tile = (float4 *)smem;
+    float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 16);
+    float *ltaps = (float *)(smem + (size_t)g.a_gran * 16 + (size_t)(NT + 2) * 8);
+    for (int i = tid; i < g.T; i += NT) ltaps[i] = taps[i];
+
+    // Per-slot constants (the same for every tile): the sample granule this lane stages in slot k
+    // and its byte offset from the tile window's first sample.  Slots past the tile are clamped
+    // to its last granule, so the fast path below is branch-free: a branch per load would make
+    // hipcc wait for each load at the join, one HBM round trip after the other.
+    P pre[SLOTS];
+    int sgk[SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int sg = sample_granule(g, k * NT + tid);
+        sgk[k] = sg < g.s_gran ? sg : g.s_gran - 1;
+    }
+    auto fetch_tile = [&](const TileRef &tr) {
+        if (tr.fast) {
+#pragma unroll
+            for (int k = 0; k < SLOTS; ++k)
+                pre[k] = *(const P *)(tr.wbase + (unsigned)sgk[k] * PairBytes<IN>::value);
+        } else {
+#pragma unroll
+            for (int k = 0; k < SLOTS; ++k)
+                pre[k] = fetch_pair_checked<IN>(g, tr.src, tr.W0 + 2LL * sgk[k]);
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, t, NT * R));
+    for (; t < g.total_tiles; t += gridDim.x) {
+        const TileRef tr = tile_ref<IN>(g, in, t, NT * R);
+        __syncthreads();                         // every lane has finished with the previous tile
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int a = k * NT + tid;
+            const float4 x = convert_pair<IN>(pre[k], g.mix_fr, tr.W0 + 2LL * sgk[k]);
+            if (a < g.a_gran) tile[a] = x;
+        }
+        __syncthreads();
+        // request the next tile now: its HBM latency is covered by the walk below
+        {
+            const int tn = t + gridDim.x;
+            if (tn < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, tn, NT * R));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        float2 acc[R];
+        walk<2, R>(g, (const uint4 *)tile, gtab, tid, acc);
+
+        const long long m0 = tr.M0 + (long long)tid * R;
+        float2 ynext = make_float2(0.f, 0.f);
+        if (g.mode == SDR_MODE_FM) {
+            ybuf[tid] = acc[0];
+            if (tid < 64) {
+                const float2 ys = successor_output<2>(g, smem, ltaps, tid, NT, R);
+                if (tid == 0) ybuf[NT] = ys;
+            }
+            __syncthreads();
+            ynext = ybuf[tid + 1];
+        }
+        store_outputs<R>(g, outv, tr.ch, m0, acc, ynext);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fir_raw_kernel: int16 IQ without mixer, raw samples in LDS (4 per granule) filled by LDS-DMA,
+// one tile per workgroup.  LDS: [tile (a_gran uint4) | ybuf (NT+2 float2)].
+// ---------------------------------------------------------------------------------------------
+// One LDS-DMA piece (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave), from inline asm so
+// that it stays off hipcc's vmcnt book-keeping; the kernel waits vmcnt(0) itself before the
+// barrier.  lds_byte must be wave-uniform (it goes to M0); M0 is saved and restored.
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte)
+                 : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)p;
+}
+
 template <int R>
 __global__ void __launch_bounds__(256)
 fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
@@ -157,24 +522,19 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     const long long W0 = M0 * g.D - g.Tback;                 // first staged sample (multiple of 4)
     const uint32_t *src = in + ch * g.in_stride;             // sample 0 of this channel
 
-    // ---- stage the tile ----------------------------------------------------------------
-    const int n_inst = g.a_gran / NT;
     const bool interior = (W0 >= g.lo_valid) && (W0 + 4LL * g.s_gran <= g.hi_valid);
     if (interior) {
         const uint32_t *wsrc = src + W0;
-        for (int k = 0; k < n_inst; ++k) {
-            const int a = k * NT + tid;
-            int sg = sample_granule(g, a);
+        for (int k = 0; k < g.n_inst; ++k) {
+            int sg = sample_granule(g, k * NT + tid);
             sg = sg < g.s_gran ? sg : 0;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc + 4 * sg),
-                                             (lds_ptr_t)(lds4 + k * NT + (tid & ~63)), 16, 0, 0);
+            dma16(wsrc + 4 * sg, __builtin_amdgcn_readfirstlane(lds_addr(lds4 + k * NT + (tid & ~63))));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-        for (int k = 0; k < n_inst; ++k) {
+        for (int k = 0; k < g.n_inst; ++k) {
             const int a = k * NT + tid;
-            const int sg = sample_granule(g, a);
-            const long long s = W0 + 4LL * sg;
+            const long long s = W0 + 4LL * sample_granule(g, a);
             uint32_t w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -186,132 +546,8 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     }
     __syncthreads();
 
-    // ---- FIR: lane window walk -----------------------------------------------------------
     float2 acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
-
-    const int lane_g = tid * (g.q + g.pad);
-    int padoff = 0, cq = 0;
-    for (int c = 0; c < g.ngran; ++c) {
-        const uint4 v = lds4[lane_g + c + padoff];
-        if (g.pad) { if (++cq == g.q) { cq = 0; ++padoff; } }
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        const float *gt = gtab + (size_t)c * (4 * R);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float xi = (float)(short)(w[u] & 0xffffu);
-            const float xq = (float)((int)w[u] >> 16);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float h = gt[u * R + r];
-                acc[r].x = __fmaf_rn(h, xi, acc[r].x);
-                acc[r].y = __fmaf_rn(h, xq, acc[r].y);
-            }
-        }
-    }
-
-    // ---- epilogue --------------------------------------------------------------------------
-    const long long m0 = M0 + (long long)tid * R;
-    float2 ynext = make_float2(0.f, 0.f);
-    if (g.mode == SDR_MODE_FM) {
-        float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 16);
-        ybuf[tid] = acc[0];
-        if (tid < 64) {
-            // successor of the tile's last output, y[M0 + NT*R], summed across the wave
-            float2 part = make_float2(0.f, 0.f);
-            const uint32_t *lds1 = (const uint32_t *)smem;
-            const int sbase = g.D * NT * R + g.Tback;      // window offset of sample D*(M0+NT*R)
-            for (int i = tid; i < g.T; i += 64) {
-                const int sidx = sbase - i;
-                const uint32_t wv = lds1[lds_granule(g, sidx >> 2) * 4 + (sidx & 3)];
-                const float h = taps[i];
-                part.x = __fmaf_rn(h, (float)(short)(wv & 0xffffu), part.x);
-                part.y = __fmaf_rn(h, (float)((int)wv >> 16), part.y);
-            }
-            part = wave_sum(part);
-            if (tid == 0) ybuf[NT] = part;
-        }
-        __syncthreads();
-        ynext = ybuf[tid + 1];
-    }
-    store_outputs<R>(g, outv, ch, m0, acc, ynext);
-}
-
-// ---------------------------------------------------------------------------------------------
-// every other input: float2 samples in LDS (8 B each, 2 per granule), staged through registers
-// with the optional NCO mixer applied once per sample.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float2 load_sample(const FirGeom &g, const void *__restrict__ src,
-                                              long long si)
-{
-    if (si < g.lo_valid || si >= g.hi_valid) return make_float2(0.f, 0.f);
-    float2 x;
-    if (g.input == SDR_IN_I16_IQ) {
-        const uint32_t w = ((const uint32_t *)src)[si];
-        x = make_float2((float)(short)(w & 0xffffu), (float)((int)w >> 16));
-    } else if (g.input == SDR_IN_CF32) {
-        x = ((const float2 *)src)[si];
-    } else {
-        x = make_float2(((const float *)src)[si], 0.f);
-    }
-    if (g.mix_fr != 0.0) {
-        // exp(+j*2*pi*fr*n): the phase in revolutions is reduced in double, so it is exact to
-        // ~1e-16*n*fr before the float sincospi
-        const double ph = g.mix_fr * (double)si;
-        const float fr = (float)(ph - rint(ph));
-        float sn, cs;
-        sincospif(2.0f * fr, &sn, &cs);
-        x = make_float2(__fmaf_rn(x.x, cs, -(x.y * sn)), __fmaf_rn(x.x, sn, x.y * cs));
-    }
-    return x;
-}
-
-template <int R>
-__global__ void __launch_bounds__(256)
-fir_f2_kernel(const void *__restrict__ inv, void *__restrict__ outv,
-              const float *__restrict__ gtab, const float *__restrict__ taps, const FirGeom g)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *lds4 = (float4 *)smem;
-    const int tid = threadIdx.x;
-    const int NT = blockDim.x;
-    const long long ch = blockIdx.y;
-    const long long M0 = g.tile0 + (long long)blockIdx.x * (NT * R);
-    const long long W0 = M0 * g.D - g.Tback;
-    const size_t esz = g.input == SDR_IN_CF32 ? 8 : 4;
-    const void *src = (const unsigned char *)inv + (size_t)(ch * g.in_stride) * esz;
-
-    const int n_inst = g.a_gran / NT;
-    for (int k = 0; k < n_inst; ++k) {
-        const int a = k * NT + tid;
-        const int sg = sample_granule(g, a);
-        const long long s = W0 + 2LL * sg;
-        const float2 x0 = load_sample(g, src, s);
-        const float2 x1 = load_sample(g, src, s + 1);
-        lds4[a] = make_float4(x0.x, x0.y, x1.x, x1.y);
-    }
-    __syncthreads();
-
-    float2 acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
-
-    const int lane_g = tid * (g.q + g.pad);
-    int padoff = 0, cq = 0;
-    for (int c = 0; c < g.ngran; ++c) {
-        const float4 v = lds4[lane_g + c + padoff];
-        if (g.pad) { if (++cq == g.q) { cq = 0; ++padoff; } }
-        const float *gt = gtab + (size_t)c * (2 * R);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float h0 = gt[r], h1 = gt[R + r];
-            acc[r].x = __fmaf_rn(h0, v.x, acc[r].x);
-            acc[r].y = __fmaf_rn(h0, v.y, acc[r].y);
-            acc[r].x = __fmaf_rn(h1, v.z, acc[r].x);
-            acc[r].y = __fmaf_rn(h1, v.w, acc[r].y);
-        }
-    }
+    walk<4, R>(g, lds4, gtab, tid, acc);
 
     const long long m0 = M0 + (long long)tid * R;
     float2 ynext = make_float2(0.f, 0.f);
@@ -319,18 +555,8 @@ fir_f2_kernel(const void *__restrict__ inv, void *__restrict__ outv,
         float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 16);
         ybuf[tid] = acc[0];
         if (tid < 64) {
-            float2 part = make_float2(0.f, 0.f);
-            const float2 *lds2 = (const float2 *)smem;
-            const int sbase = g.D * NT * R + g.Tback;
-            for (int i = tid; i < g.T; i += 64) {
-                const int sidx = sbase - i;
-                const float2 x = lds2[lds_granule(g, sidx >> 1) * 2 + (sidx & 1)];
-                const float h = taps[i];
-                part.x = __fmaf_rn(h, x.x, part.x);
-                part.y = __fmaf_rn(h, x.y, part.y);
-            }
-            part = wave_sum(part);
-            if (tid == 0) ybuf[NT] = part;
+            const float2 ys = successor_output<4>(g, smem, taps, tid, NT, R);
+            if (tid == 0) ybuf[NT] = ys;
         }
         __syncthreads();
         ynext = ybuf[tid + 1];
@@ -345,10 +571,11 @@ fir_f2_kernel(const void *__restrict__ inv, void *__restrict__ outv,
 // =============================================================================================
 struct sdr_fir_plan {
     int input, mode, D, T, R, NT;
-    bool raw;               // raw int16 LDS kernel (int16 input, mixer off)
+    bool raw;               // fir_raw_kernel (else fir_stream_kernel)
     double scale, mix_fr;
-    int Tback, Lw4, ngran, q, pad, s_gran, a_gran, lds_bytes, spg;   // spg: samples per granule
-    unsigned magic;
+    int spg;                // samples per LDS granule: 4 (raw) / 2 (stream)
+    int Tback, Lw4, ngran, q, pad, s_gran, a_gran, n_inst, lds_bytes;
+    int stream_blocks = 0;  // persistent grid: CUs x resident workgroups per CU
     float *d_gtab = nullptr, *d_taps = nullptr;
     // staging buffers for the *_host entry point
     void *d_in = nullptr, *d_out = nullptr;
@@ -360,48 +587,63 @@ namespace {
 
 int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
-bool r_allowed(int D, int R, int spg) { return ((long long)D * R) % spg == 0; }
+struct Geometry { int Tback, Lw4, U, ngran, look, q, pad, s_gran, a_gran, n_inst, lds_bytes; };
 
-int window_len(int T, int D, int R) { return roundup(roundup(T - 1, 4) + D * (R - 1) + 1, 4); }
-
-// LDS bytes of one workgroup for a given geometry (tile + discriminator hand-off buffer)
-void tile_geometry(int T, int D, int R, int NT, int spg, int *q, int *pad, int *s_gran,
-                   int *a_gran, int *lds_bytes)
+// Tile geometry for (T, D, R, NT) with spg samples per LDS granule.  Returns false when the lane
+// stride is not a whole number of granules.
+bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *o)
 {
-    const int Tback = roundup(T - 1, 4);
-    const int Lw4 = window_len(T, D, R);
-    *q = D * R / spg;
-    *pad = (*q % 2 == 0) ? 1 : 0;
-    const long long s_need = (long long)D * R * (NT - 1) + Lw4;
-    const long long s_fm = (long long)D * R * NT + Tback + 1;
+    if (((long long)D * R) % spg) return false;
+    o->Tback = roundup(T - 1, 4);
+    o->Lw4 = roundup(o->Tback + D * (R - 1) + 1, 4);
+    o->U = (spg * R >= 16) ? 1 : 16 / (spg * R);
+    const int steps = roundup((o->Lw4 / spg + o->U - 1) / o->U, 2);
+    o->ngran = steps * o->U;                  // granules walked (padded with zero taps)
+    o->look = o->U;                           // one look-ahead step is loaded, never used
+    o->q = D * R / spg;
+    o->pad = (o->q % 2 == 0) ? 1 : 0;
+    const long long s_need = (long long)D * R * (NT - 1) + (long long)(o->ngran + o->look) * spg;
+    const long long s_fm = (long long)D * R * NT + o->Tback + 1;
     const long long s_tile = s_need > s_fm ? s_need : s_fm;
-    *s_gran = (int)((s_tile + spg - 1) / spg);
-    int a = *s_gran + (*pad ? *s_gran / *q + 1 : 0);
-    *a_gran = roundup(a, NT);
-    *lds_bytes = *a_gran * 16 + (NT + 1) * 8;
+    if (s_tile > (1LL << 22)) return false;
+    o->s_gran = (int)((s_tile + spg - 1) / spg);
+    const int a = o->s_gran + (o->pad ? o->s_gran / o->q + 1 : 0);
+    o->a_gran = roundup(a, NT);
+    o->n_inst = o->a_gran / NT;
+    o->lds_bytes = o->a_gran * 16 + (NT + 2) * 8 + (stream ? roundup(T, 4) * 4 : 0);
+    return true;
 }
 
+size_t in_elem_bytes(int input) { return input == SDR_IN_CF32 ? 8 : 4; }
+size_t out_elem_bytes(int mode) { return mode == SDR_MODE_IQ ? 8 : 4; }
+
 template <int R>
-hipError_t launch_r(const sdr_fir_plan *p, dim3 grid, hipStream_t st, const void *in, void *out,
-                    const FirGeom &g)
+hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void *out,
+                    const FirGeom &g, unsigned tiles, unsigned n_ch)
 {
     if (p->raw) {
         if (p->lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)fir_raw_kernel<R>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
-        fir_raw_kernel<R><<<grid, p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_gtab,
-                                                            p->d_taps, g);
-    } else {
-        if (p->lds_bytes > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)fir_f2_kernel<R>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
-        fir_f2_kernel<R><<<grid, p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, p->d_taps, g);
+        fir_raw_kernel<R><<<dim3(tiles, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
+                                                                        p->d_gtab, p->d_taps, g);
+        return hipGetLastError();
     }
+    const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
+#define SDR_STREAM(INK, SL)                                                                      \
+    do {                                                                                         \
+        if (p->lds_bytes > 64 * 1024)                                                            \
+            (void)hipFuncSetAttribute((const void *)fir_stream_kernel<INK, R, SL>,               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes); \
+        fir_stream_kernel<INK, R, SL><<<nb, p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, p->d_taps, g); \
+    } while (0)
+    const bool small = p->n_inst <= kSlotsSmall;
+    if (p->input == SDR_IN_I16_IQ) { if (small) SDR_STREAM(IN_I16, kSlotsSmall); else SDR_STREAM(IN_I16, kSlots); }
+    else if (p->input == SDR_IN_CF32) { if (small) SDR_STREAM(IN_CF32, kSlotsSmall); else SDR_STREAM(IN_CF32, kSlots); }
+    else { if (small) SDR_STREAM(IN_REAL, kSlotsSmall); else SDR_STREAM(IN_REAL, kSlots); }
+#undef SDR_STREAM
     return hipGetLastError();
 }
-
-size_t in_elem_bytes(int input) { return input == SDR_IN_CF32 ? 8 : 4; }
-size_t out_elem_bytes(int mode) { return mode == SDR_MODE_IQ ? 8 : 4; }
 
 // Enqueue one launch.  `in` points at stream sample index in_first of channel 0.
 int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resident,
@@ -423,20 +665,23 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.out_end = out_end;
     g.mix_fr = p->mix_fr;
     g.D = p->D; g.T = p->T; g.Tback = p->Tback; g.ngran = p->ngran; g.q = p->q; g.pad = p->pad;
-    g.magic = p->magic; g.s_gran = p->s_gran; g.a_gran = p->a_gran; g.mode = p->mode;
-    g.input = p->input; g.scale = (float)p->scale;
+    g.magic = (unsigned)((0x100000000ULL + (unsigned)p->q) / (unsigned)(p->q + 1));
+    g.magic_q = (unsigned)((0x100000000ULL + (unsigned)p->q - 1) / (unsigned)p->q);
+    g.s_gran = p->s_gran; g.a_gran = p->a_gran; g.n_inst = p->n_inst; g.mode = p->mode;
+    g.scale = (float)p->scale;
     const long long per_tile = (long long)p->NT * p->R;
     const long long tiles = (out_end - g.tile0 + per_tile - 1) / per_tile;
-    if (tiles > 0x7fffffffLL) { sdr::set_error("too many tiles"); return SDR_EINVAL; }
+    if (tiles * (long long)n_ch > 0x7fffffffLL) { sdr::set_error("too many tiles"); return SDR_EINVAL; }
+    g.tiles_per_ch = (int)tiles;
+    g.total_tiles = (int)(tiles * (long long)n_ch);
     // virtual pointer to stream sample 0 of channel 0 (only dereferenced inside the valid window)
     const void *base = (const unsigned char *)in - (size_t)in_first * in_elem_bytes(p->input);
-    dim3 grid((unsigned)tiles, (unsigned)n_ch);
     hipError_t e;
     switch (p->R) {
-    case 1: e = launch_r<1>(p, grid, st, base, out, g); break;
-    case 2: e = launch_r<2>(p, grid, st, base, out, g); break;
-    case 4: e = launch_r<4>(p, grid, st, base, out, g); break;
-    default: e = launch_r<8>(p, grid, st, base, out, g); break;
+    case 1: e = launch_r<1>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
+    case 2: e = launch_r<2>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
+    case 4: e = launch_r<4>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
+    default: e = launch_r<8>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
     }
     if (e != hipSuccess) return sdr::hip_fail(e, "fir kernel launch");
     return SDR_OK;
@@ -462,64 +707,95 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->n_taps > 16384) { sdr::set_error("n_taps > 16384 unsupported"); return SDR_EINVAL; }
     if (d->input < SDR_IN_I16_IQ || d->input > SDR_IN_F32_REAL) { sdr::set_error("bad input kind"); return SDR_EINVAL; }
     if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_ENV) { sdr::set_error("bad mode"); return SDR_EINVAL; }
+    if (d->pipeline < 0 || d->pipeline > 2) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
 
     sdr_fir_plan *p = new sdr_fir_plan();
     p->input = d->input; p->mode = d->mode; p->D = d->decim; p->T = d->n_taps;
     p->scale = d->scale; p->mix_fr = d->mix_fr;
-    p->raw = (d->input == SDR_IN_I16_IQ && d->mix_fr == 0.0);
-    p->spg = p->raw ? 4 : 2;
     (void)hipGetDevice(&p->device);
+    const bool raw_possible = (d->input == SDR_IN_I16_IQ && d->mix_fr == 0.0);
+    if (d->pipeline == 1 && !raw_possible) { delete p; sdr::set_error("pipeline 1 needs int16 input without mixer"); return SDR_EINVAL; }
 
-    // ---- choose outputs per lane (R) and workgroup size (NT) --------------------------------
+    // ---- choose kernel, outputs per lane (R) and workgroup size (NT) ------------------------
+    // cost model (SIMD cycles per output, gfx950 measured issue costs: v_pk_fma_f32 4 cycles per
+    // two MACs, v_cvt_f32_i32 4 cycles): stream = FMAs only (conversion amortised over the tile),
+    // raw = FMAs + two conversions per sample read; plus the LDS read of the window per output.
     const int Rs[4] = {1, 2, 4, 8};
     const int NTs[3] = {256, 128, 64};
+    Geometry best{};
     int bestR = 0, bestNT = 0;
+    bool best_raw = false;
     double best_cost = 0;
-    for (int ri = 0; ri < 4; ++ri) {
-        const int R = Rs[ri];
-        if (d->outputs_per_lane && d->outputs_per_lane != R) continue;
-        if (!r_allowed(p->D, R, p->spg)) continue;
-        const int Lw4 = window_len(p->T, p->D, R);
-        // VALU lane-ops per output: conversions (raw only) + 2 FMAs per (sample, output)
-        const double cost = (double)Lw4 * ((p->raw ? 2.0 : 0.0) + 2.0 * R) / R;
-        for (int ni = 0; ni < 3; ++ni) {
-            const int NT = NTs[ni];
-            if (d->threads && d->threads != NT) continue;
-            int q, pad, sg, ag, lds;
-            tile_geometry(p->T, p->D, R, NT, p->spg, &q, &pad, &sg, &ag, &lds);
-            const int budget = d->threads || ni == 2 ? 160 * 1024 : 52 * 1024;   // >= 3 WGs per CU
-            if (lds > budget) continue;
-            if (!bestR || cost < best_cost * 0.97) { bestR = R; bestNT = NT; best_cost = cost; }
-            break;
+    // Kernel kinds in order of preference: measured on MI355X the raw-tile kernel is the faster one
+    // for int16 input (6 resident workgroups per CU instead of 3), so the
+    // streaming kernel is the automatic choice only for the inputs the raw kernel cannot take
+    // or when no raw geometry fits.
+    for (int pass = 0; pass < 2 && !bestR; ++pass) {
+        const bool raw = (pass == 0) ? raw_possible : !raw_possible;
+        if (raw && (!raw_possible || d->pipeline == 2)) continue;
+        if (!raw && d->pipeline == 1) continue;
+        const int spg = raw ? 4 : 2;
+        for (int ri = 0; ri < 4; ++ri) {
+            const int R = Rs[ri];
+            if (d->outputs_per_lane && d->outputs_per_lane != R) continue;
+            for (int ni = 0; ni < 3; ++ni) {
+                const int NT = NTs[ni];
+                if (d->threads && d->threads != NT) continue;
+                Geometry gm;
+                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm)) break;
+                if (!raw && gm.n_inst > kSlots) continue;
+                const bool forced = d->threads != 0;
+                // automatic choice: raw tiles <= 27 KB (6 workgroups per CU), float tiles <= 53 KB (3)
+                const int budget = (forced || ni == 2) ? 160 * 1024 : (raw ? 27 : 53) * 1024;
+                if (gm.lds_bytes > budget) continue;
+                // SIMD cycles per output (gfx950: v_pk_fma_f32 and v_cvt_f32_i32 issue in 4 cycles):
+                // one packed FMA per (sample, output), two conversions per sample read (raw only),
+                // one ds_read_b128 per granule
+                const double walked = (double)gm.ngran * spg;                  // samples per lane
+                double cost = walked * (4.0 + (raw ? 8.0 : 0.0) / R) + walked / spg * 4.0 / R;
+                if (gm.pad) cost *= 1.1;                                       // padded image: extra index work
+                if (ni > 0) cost *= 1.05;                                      // smaller tiles: more halo
+                if (!bestR || cost < best_cost) { best = gm; bestR = R; bestNT = NT; best_raw = raw; best_cost = cost; }
+                break;
+            }
         }
     }
     if (!bestR) {
         delete p;
-        sdr::set_error("no kernel geometry for decim=%d taps=%d (outputs_per_lane=%d threads=%d)",
-                       d->decim, d->n_taps, d->outputs_per_lane, d->threads);
+        sdr::set_error("no kernel geometry for decim=%d taps=%d (outputs_per_lane=%d threads=%d pipeline=%d)",
+                       d->decim, d->n_taps, d->outputs_per_lane, d->threads, d->pipeline);
         return SDR_EINVAL;
     }
-    p->R = bestR; p->NT = bestNT;
-    p->Tback = roundup(p->T - 1, 4);
-    p->Lw4 = window_len(p->T, p->D, p->R);
-    p->ngran = p->Lw4 / p->spg;
-    tile_geometry(p->T, p->D, p->R, p->NT, p->spg, &p->q, &p->pad, &p->s_gran, &p->a_gran,
-                  &p->lds_bytes);
-    p->magic = (unsigned)((0x100000000ULL + (unsigned)p->q) / (unsigned)(p->q + 1));  // ceil(2^32/(q+1))
+    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->spg = best_raw ? 4 : 2;
+    p->Tback = best.Tback; p->Lw4 = best.Lw4; p->ngran = best.ngran; p->q = best.q; p->pad = best.pad;
+    p->s_gran = best.s_gran; p->a_gran = best.a_gran; p->n_inst = best.n_inst; p->lds_bytes = best.lds_bytes;
+    {
+        hipDeviceProp_t prop;
+        int ncu = 256;
+        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) ncu = prop.multiProcessorCount;
+        int per_cu = (160 * 1024) / p->lds_bytes;
+        const int wave_cap = 32 / (p->NT / 64);
+        if (per_cu > wave_cap) per_cu = wave_cap;
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        p->stream_blocks = ncu * per_cu;
+    }
 
     // ---- tap tables ---------------------------------------------------------------------------
     // taps rounded to float32; for int16 input the exact 2^-11 Q11 scale is folded in
     const float fold = (p->input == SDR_IN_I16_IQ) ? sdr::kQ11 : 1.0f;
     std::vector<float> hf(p->T);
     for (int i = 0; i < p->T; ++i) hf[i] = (float)d->taps[i] * fold;
-    // gtab[j][r] = h[D*r + Tback - j]  (tap that window offset j contributes to output r)
-    std::vector<float> gt((size_t)p->Lw4 * p->R, 0.0f);
-    for (int j = 0; j < p->Lw4; ++j)
+    // gtab[j][r] = h[D*r + Tback - j]  (tap that window offset j contributes to output r);
+    // rows past the window (padding + look-ahead step) stay zero
+    const size_t rows = (size_t)(best.ngran + best.look) * p->spg;
+    std::vector<float> gt(rows * p->R, 0.0f);
+    for (size_t j = 0; j < rows; ++j)
         for (int r = 0; r < p->R; ++r) {
-            const long long i = (long long)p->D * r + p->Tback - j;
-            if (i >= 0 && i < p->T) gt[(size_t)j * p->R + r] = hf[i];
+            const long long i = (long long)p->D * r + p->Tback - (long long)j;
+            if (i >= 0 && i < p->T) gt[j * p->R + r] = hf[i];
         }
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_taps, hf.size() * sizeof(float));
@@ -558,10 +834,15 @@ extern "C" int sdr_fir_plan_info(const sdr_fir_plan *p, int *R, int *NT, int *ld
     return SDR_OK;
 }
 
+extern "C" int sdr_fir_plan_kernel(const sdr_fir_plan *p)
+{
+    return p ? (p->raw ? 1 : 2) : 0;
+}
+
 extern "C" int sdr_fir_execute_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, void *d_out,
                                    size_t out_capacity, size_t *n_out, void *stream)
 {
-    if (!p || (!d_in && n_in) ) { sdr::set_error("null argument"); return SDR_EINVAL; }
+    if (!p || (!d_in && n_in)) { sdr::set_error("null argument"); return SDR_EINVAL; }
     const long long cnt = out_count(p, (long long)n_in);
     if (n_out) *n_out = (size_t)cnt;
     if ((size_t)cnt > out_capacity) { sdr::set_error("output capacity %zu < %lld", out_capacity, cnt); return SDR_ECAPACITY; }
@@ -601,7 +882,6 @@ extern "C" int sdr_fir_execute_batched_dev(sdr_fir_plan *p, const void *d_in, si
     if (!p || !d_in || !d_out) { sdr::set_error("null argument"); return SDR_EINVAL; }
     const long long cnt = out_count(p, (long long)n_in);
     if (n_channels > 1 && (in_stride < n_in || out_stride < (size_t)cnt)) { sdr::set_error("channel stride smaller than channel length"); return SDR_EINVAL; }
-    if (in_elem_bytes(p->input) == 8 ? false : false) {}
     return launch(p, d_in, 0, (long long)n_in, (long long)n_in, 0, cnt, (long long)in_stride,
                   n_channels, d_out, (long long)out_stride, (hipStream_t)stream);
 }

@@ -55,7 +55,7 @@ def test_bad_arguments_without_device(capi):
     assert L.sdr_create_fir_filter(C.c_size_t(0), C.c_double(0.1), C.c_int(1), None) == capi.EINVAL
     # the reference throws std::invalid_argument for D <= 0 (bladerf_apt_demod.cpp:254-255)
     taps = np.ones(4)
-    d = capi.FirDesc(0, 1, 0, 4, taps.ctypes.data_as(C.POINTER(C.c_double)), 1.0, 0.0, 0, 0)
+    d = capi.FirDesc(0, 1, 0, 4, taps.ctypes.data_as(C.POINTER(C.c_double)), 1.0, 0.0, 0, 0, 0)
     h = C.c_void_p()
     assert L.sdr_fir_plan_create(C.byref(d), C.byref(h)) == capi.EINVAL
     assert b"positive" in L.sdr_last_error()

@@ -176,18 +176,22 @@ def test_geometries_against_oracle(sdr, oracle, T, D):
     ran = 0
     for R in (1, 2, 4, 8):
         for NT in (64, 128, 256):
-            try:
-                p_fm = sdr.FirPlan(h, D, mode=sdr.MODE_FM, outputs_per_lane=R, threads=NT)
-            except sdr.SdrError as e:
-                assert e.status == sdr.capi.EINVAL       # geometry not available (alignment / LDS)
-                continue
-            ran += 1
-            tag = f"T={T} D={D} R={R} NT={NT}"
-            check_fm(p_fm.execute_host(iq), fm, y, 1 / TWO_PI, tag)
-            check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_ENV, outputs_per_lane=R,
-                                     threads=NT).execute_host(iq), env, tag)
-            check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_IQ, outputs_per_lane=R,
-                                     threads=NT).execute_host(iq), y, tag)
+            for pipe in (1, 2):      # one tile per workgroup / persistent double-buffered
+                try:
+                    p_fm = sdr.FirPlan(h, D, mode=sdr.MODE_FM, outputs_per_lane=R, threads=NT,
+                                       pipeline=pipe)
+                except sdr.SdrError as e:
+                    assert e.status == sdr.capi.EINVAL   # geometry not available (alignment / LDS)
+                    continue
+                if pipe == 2 and p_fm.info()["lds_bytes"] > 160 * 1024:
+                    continue
+                ran += 1
+                tag = f"T={T} D={D} R={R} NT={NT} pipe={pipe}"
+                check_fm(p_fm.execute_host(iq), fm, y, 1 / TWO_PI, tag)
+                check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_ENV, outputs_per_lane=R, threads=NT,
+                                         pipeline=pipe).execute_host(iq), env, tag)
+                check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_IQ, outputs_per_lane=R, threads=NT,
+                                         pipeline=pipe).execute_host(iq), y, tag)
     assert ran >= 3
 
 

@@ -30,15 +30,18 @@ def main():
         bps = 4.0 + (8.0 if mode == 0 else 4.0) / D
         for R in (1, 2, 4, 8):
             for NT in (64, 128, 256):
-                try:
-                    p = sdr_amd.FirPlan(h, D, mode=mode, outputs_per_lane=R, threads=NT)
-                except sdr_amd.SdrError:
-                    continue
-                p.time_dev(d_in, n, d_out, 2)
-                ms = p.time_dev(d_in, n, d_out, 10)
-                print(f"T={T} D={D} mode={mode} R={R} NT={NT} lds={p.info()['lds_bytes']:6d} "
-                      f"ms={ms:8.4f} MS/s={n / ms / 1e3:10.0f} GB/s={bps * n / ms / 1e6:8.1f}", flush=True)
-                p.destroy()
+                for pipe in (1, 2):
+                    try:
+                        p = sdr_amd.FirPlan(h, D, mode=mode, outputs_per_lane=R, threads=NT, pipeline=pipe)
+                    except sdr_amd.SdrError:
+                        continue
+                    if pipe == 2 and p.info()['lds_bytes'] > 160 * 1024:
+                        continue
+                    p.time_dev(d_in, n, d_out, 2)
+                    ms = p.time_dev(d_in, n, d_out, 10)
+                    print(f"T={T} D={D} mode={mode} R={R} NT={NT} pipe={pipe} lds={p.info()['lds_bytes']:6d} "
+                          f"ms={ms:8.4f} MS/s={n / ms / 1e3:10.0f} GB/s={bps * n / ms / 1e6:8.1f}", flush=True)
+                    p.destroy()
 
 
 if __name__ == "__main__":

@@ -185,6 +185,33 @@ int sdr_unpack_i16_dev(const int16_t *d_iq, size_t n, float *d_cf32, void *strea
 int sdr_frequency_shift_dev(const float *d_in, int is_complex, size_t n, uint64_t n0, double fr,
                             float *d_out_cf32, void *stream);
 
+/* ---- a8 support: gather --------------------------------------------------------------------
+ * out[i] = in[idx[i]] for elements of elem_dwords 32-bit words.  decimate_vec
+ * (bladerf_apt_demod.cpp:374-401; cv_decimate, opencv_complex_functions.h:22-61) is this gather
+ * with the reference's index sequence floor(0), floor(rate), floor(rate+rate), ... which the
+ * C++ shim builds on the host exactly as the reference accumulates it. */
+int sdr_gather_dev(const void *d_in, int elem_dwords, size_t n_in, const uint64_t *d_idx,
+                   size_t n_idx, void *d_out, void *stream);
+
+/* ---- a12: block hand-off with persistent filter history ------------------------------------
+ * Replaces SDR_BASE::start / wait_for_samples / stop (sdr_base.h:42-55), the capture thread's
+ * buffer hand-off (bladerf_sdr.h:270-302) and apt_demod's iq_data_queue double buffer
+ * (bladerf_apt_demod.cpp:64-71,152-178).  The producer pushes blocks of the plan's input type
+ * (host memory); each is copied through pinned staging to the device behind the FIR history of
+ * the previous block and filtered asynchronously on the stream's own HIP stream, so block
+ * boundaries leave no transient (the reference restarts every block from zero state).  pop()
+ * waits for the oldest block and returns the outputs that became computable with it; over all
+ * blocks the popped outputs concatenate to exactly the one-shot result on the concatenated
+ * input.  Two blocks may be in flight; a third push returns SDR_ECAPACITY.  Single producer /
+ * single consumer thread, like the reference. */
+typedef struct sdr_fir_stream sdr_fir_stream;
+int sdr_fir_stream_create(sdr_fir_plan *plan, size_t max_block_samples, sdr_fir_stream **stream);
+int sdr_fir_stream_destroy(sdr_fir_stream *stream);
+int sdr_fir_stream_push(sdr_fir_stream *stream, const void *block_host, size_t n_samples);
+int sdr_fir_stream_pop(sdr_fir_stream *stream, void *out_host, size_t capacity, size_t *n_out);
+/* input kind, mode, decimation and tap count of a plan */
+int sdr_fir_plan_shape(const sdr_fir_plan *plan, int *input, int *mode, int *decim, int *n_taps);
+
 /* ---- synthetic input (test/bench support; no reference counterpart) --------------------------
  * Writes n int16 IQ samples of an FM-modulated tone, stream indices n0 .. n0+n-1:
  * phi = (dev/ftone)*sin(2*pi*ftone*t/fs), I = round(amp*cos phi), Q = round(amp*sin phi), plus

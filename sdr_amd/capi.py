@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdrhip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "lib.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "stream.hip", "lib.hip")]
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 OK, EINVAL, ENOMEM, EHIP, EALIGN, ECAPACITY, ENODEV, ERANGE = range(8)
@@ -308,3 +308,35 @@ def synth_fm_i16_dev(d_iq, n, n0=0, fs=1.0e6, ftone=1000.0, dev=5000.0, amp=2000
     check(lib().sdr_synth_fm_i16_dev(_vp(d_iq), C.c_size_t(n), C.c_uint64(n0), C.c_double(fs),
                                      C.c_double(ftone), C.c_double(dev), C.c_double(amp),
                                      C.c_int(noise_lsb), C.c_uint(seed), C.c_void_p(stream or 0)))
+
+
+class FirStream:
+    """sdr_fir_stream: push blocks, pop outputs; filter history persists across blocks."""
+
+    def __init__(self, plan, max_block_samples):
+        self.plan = plan
+        self.h = C.c_void_p()
+        check(lib().sdr_fir_stream_create(plan.h, C.c_size_t(max_block_samples), C.byref(self.h)))
+        self._cap = max_block_samples // plan.decim + 8 + 4096
+
+    def push(self, block):
+        a, n = self.plan._in_array(block)
+        check(lib().sdr_fir_stream_push(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+
+    def pop(self):
+        out = np.empty(self._cap, self.plan.out_dtype)
+        n = C.c_size_t()
+        check(lib().sdr_fir_stream_pop(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(self._cap),
+                                       C.byref(n)))
+        return out[: n.value].copy()
+
+    def destroy(self):
+        if self.h and self.h.value:
+            lib().sdr_fir_stream_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -834,6 +834,16 @@ extern "C" int sdr_fir_plan_info(const sdr_fir_plan *p, int *R, int *NT, int *ld
     return SDR_OK;
 }
 
+extern "C" int sdr_fir_plan_shape(const sdr_fir_plan *p, int *input, int *mode, int *decim, int *n_taps)
+{
+    if (!p) return SDR_EINVAL;
+    if (input) *input = p->input;
+    if (mode) *mode = p->mode;
+    if (decim) *decim = p->D;
+    if (n_taps) *n_taps = p->T;
+    return SDR_OK;
+}
+
 extern "C" int sdr_fir_plan_kernel(const sdr_fir_plan *p)
 {
     return p ? (p->raw ? 1 : 2) : 0;

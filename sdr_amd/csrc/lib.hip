@@ -232,6 +232,19 @@ __global__ void __launch_bounds__(256) synth_fm_kernel(uint32_t *__restrict__ ou
     }
 }
 
+// a8 support: out[i] = in[idx[i]], elements of `ew` 32-bit words (decimate_vec's pick)
+__global__ void __launch_bounds__(256) gather_kernel(const uint32_t *__restrict__ in, int ew,
+                                                     const unsigned long long *__restrict__ idx, size_t n,
+                                                     uint32_t *__restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t total = n * (size_t)ew;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t e = i / ew, w = i - e * ew;
+        out[i] = in[idx[e] * ew + w];
+    }
+}
+
 unsigned stream_grid(size_t work_items)
 {
     size_t blocks = (work_items + 255) / 256;
@@ -289,6 +302,21 @@ extern "C" int sdr_synth_fm_i16_dev(int16_t *d_iq, size_t n, uint64_t n0, double
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
     synth_fm_kernel<<<stream_grid(n), 256, 0, (hipStream_t)stream>>>((uint32_t *)d_iq, n, n0, fs, ftone, dev, amp, noise_lsb, seed);
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+extern "C" int sdr_gather_dev(const void *d_in, int elem_dwords, size_t n_in, const uint64_t *d_idx,
+                              size_t n_idx, void *d_out, void *stream)
+{
+    (void)n_in;
+    if (n_idx == 0) return SDR_OK;
+    if (!d_in || !d_idx || !d_out || elem_dwords <= 0) { sdr::set_error("bad argument"); return SDR_EINVAL; }
+    if (((uintptr_t)d_in) & 3 || ((uintptr_t)d_out) & 3 || ((uintptr_t)d_idx) & 7) return SDR_EALIGN;
+    int rc = sdr::ensure_device();
+    if (rc != SDR_OK) return rc;
+    gather_kernel<<<stream_grid(n_idx * elem_dwords), 256, 0, (hipStream_t)stream>>>(
+        (const uint32_t *)d_in, elem_dwords, (const unsigned long long *)d_idx, n_idx, (uint32_t *)d_out);
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }

@@ -1,0 +1,88 @@
+"""GPU tests of the drop-in boundary: the reference's C++ call sites recompiled against the shim
+header (examples/apt_chain_example.cpp, built by __graft_entry__.build()), and the block
+hand-off with persistent filter history (sdr_fir_stream_*)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXAMPLE = os.path.join(ROOT, "examples", "bin", "apt_chain_example")
+
+
+@pytest.fixture(scope="module")
+def sdr():
+    import sdr_amd
+    sdr_amd.init(0)
+    return sdr_amd
+
+
+def test_reference_loop_through_shims(golden, oracle, tmp_path):
+    """bladerf_apt_demod.cpp:728-754 compiled against include/sdr_hip_shims.hpp vs the golden
+    outputs of the reference's own functions."""
+    assert os.path.exists(EXAMPLE), "run __graft_entry__.build() first"
+    src = tmp_path / "apt.sc16"
+    golden["apt_iq"].tofile(src)
+    pfx = str(tmp_path / "out")
+    r = subprocess.run([EXAMPLE, str(src), pfx], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    x6 = np.fromfile(pfx + ".x6.f64", np.float64)
+    x9 = np.fromfile(pfx + ".x9.f64", np.float64)
+    x6f = np.fromfile(pfx + ".x6f.f32", np.float32).astype(np.float64)
+    x9f = np.fromfile(pfx + ".x9f.f32", np.float32).astype(np.float64)
+    w6, w9 = golden["apt_x6"], golden["apt_x9"]
+    assert x6.shape == w6.shape == x6f.shape and x9.shape == w9.shape == x9f.shape
+    tol = 1e-5 * 0.5
+    settle = 200 // 10 + 2          # near-zero |y| during the filter's start-up: ill-conditioned angles
+    s9 = settle // 15 + 2 + 195 // 15
+    for got6, got9 in ((x6, x9), (x6f, x9f)):
+        assert np.abs(got6 - w6)[settle:].max() <= tol
+        assert np.abs(got9 - w9)[s9:].max() <= tol
+    # decimate_vec (rate 2.5) and filter_vec (7 taps) on the shim path's x6, against the oracle
+    dec = np.fromfile(pfx + ".dec.f64", np.float64)
+    want_dec, _, oob = oracle.decimate_vec(x6, 2.5)
+    assert oob == 0 and np.array_equal(dec, want_dec)             # a pick: bit exact
+    filt = np.fromfile(pfx + ".filt.f64", np.float64)
+    want_filt = oracle.filter_vec(x6, [0.1, -0.2, 0.3, 0.4, 0.3, -0.2, 0.1])
+    assert np.abs(filt - want_filt).max() <= 1e-6
+    assert np.array_equal(filt[-3:], want_filt[-3:])              # the reference's truncated tail rows
+
+
+@pytest.mark.parametrize("mode", ["fm", "env", "iq"])
+def test_stream_blocks_equal_one_shot(sdr, oracle, mode):
+    """a12: pushing blocks through sdr_fir_stream gives the one-shot result on the concatenation
+    (history carried across blocks), whatever the block sizes."""
+    m = {"fm": sdr.MODE_FM, "env": sdr.MODE_ENV, "iq": sdr.MODE_IQ}[mode]
+    n = 700_001
+    D, T = 10, 101
+    iq = oracle.synth_fm_i16(n, fs=2.0e6, ftone=1700.0, dev=25000.0)
+    h = oracle.create_fir_filter(T, 0.09, "hann")
+    plan = sdr.FirPlan(h, D, mode=m)
+    whole = plan.execute_host(iq)
+    stream = sdr.FirStream(plan, 131072)
+    rng = np.random.default_rng(7)
+    pos, parts, in_flight = 0, [], 0
+    while pos < n:
+        blk = int(min(n - pos, rng.choice([131072, 65536, 1000, 37, 9, 131071])))
+        stream.push(iq[2 * pos: 2 * (pos + blk)])
+        pos += blk
+        in_flight += 1
+        if in_flight == 2:
+            parts.append(stream.pop())
+            in_flight -= 1
+    while in_flight:
+        parts.append(stream.pop())
+        in_flight -= 1
+    got = np.concatenate(parts)
+    assert got.shape == whole.shape
+    if mode == "iq":
+        assert np.abs(got - whole).max() <= 1e-6
+    else:
+        assert np.abs(got - whole).max() <= 2e-6
+    assert (got == whole).mean() > 0.99
+    # the reference's per-block restart differs from this at every block start (the transient)
+    with pytest.raises(sdr.SdrError):
+        stream.push(iq[: 2 * 10]); stream.push(iq[: 2 * 10]); stream.push(iq[: 2 * 10])

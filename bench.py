@@ -99,11 +99,13 @@ def main():
     plan = sdr_amd.FirPlan(taps, D, mode=sdr_amd.MODE_FM, scale=1.0 / (2.0 * np.pi),
                            outputs_per_lane=a.outputs_per_lane, threads=a.threads,
                            pipeline=a.pipeline)
+    from sdr_amd import shard
+    shards = shard.plan_time_shards(n_total, D, T, shard.MODE_FM, world)
+    me = shards[rank]                          # this rank's slice of the final output
     cnt_total = plan.out_count(n_total)
-    ob = cnt_total * rank // world             # this rank's slice of the final output
-    oe = cnt_total * (rank + 1) // world
-    lo = max(0, ob * D - (T - 1))              # resident window = own block + FIR history halo
-    hi = min(n_total, (oe + 1) * D + 1)
+    assert shards[-1].out_end == cnt_total
+    ob, oe = me.out_begin, me.out_end
+    lo, hi = me.lo, me.hi                      # resident window = own block + FIR history halo
     n_res = hi - lo
 
     st = torch.cuda.current_stream().cuda_stream
@@ -163,14 +165,14 @@ def main():
     gather_ms = None
     if dist and not a.no_gather:
         # final collection of the decimated output on rank 0 over xGMI (RCCL gather), once per job
-        m = max((cnt_total * (r + 1) // world) - (cnt_total * r // world) for r in range(world))
-        send = d_out[:m].contiguous()
-        recv = [torch.empty(m, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+        counts = [sh.n_out for sh in shards]
         torch.cuda.synchronize(); dist.barrier()
         g0 = time.perf_counter()
-        dist.gather(send, recv, dst=0)
+        gathered = shard.gather_outputs(d_out, counts, dist, dst=0)
         torch.cuda.synchronize(); dist.barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert gathered.numel() == cnt_total
 
     if rank == 0:
         value = n_blk * world * a.steps / dt / 1e6

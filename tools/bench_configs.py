@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Secondary benchmarks for the other BASELINE.json configs on one GPU (the headline metric is
+bench.py).  One JSON line per config: kernel time from HIP events on the launch stream,
+algorithmic bytes / time against the 8 TB/s HBM peak, and a spot parity check
+against the CPU oracle.
+
+  cfg3  1024 independent channels x 2^20 samples, 64 taps /10, FM            (4.4 B/sample)
+  cfg4  4096-point Blackman FFT -> dB, hop 2048, 2^28 samples                (12 B/sample)
+  cfg5  APT path: 511 taps /10 FM, +2400/62400 mix, 511 taps /15, envelope   (4.03 B/sample)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sdr_amd  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+PEAK = 8000.0
+
+
+def line(name, samples, ms, bytes_per_sample, extra):
+    gbs = bytes_per_sample * samples / (ms * 1e-3) / 1e9
+    out = {"config": name, "Msamples_per_s": round(samples / ms / 1e3, 1), "kernel_ms": round(ms, 4),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK, "unit": "GB/s",
+                        "frac": round(gbs / PEAK, 4), "algorithmic_bytes_per_sample": bytes_per_sample}}
+    out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def cfg3(iters):
+    n_ch, n, D, T = 1024, 1 << 20, 10, 64
+    h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
+    plan = sdr_amd.FirPlan(h, D, mode=sdr_amd.MODE_FM)
+    d_in = sdr_amd.DevBuf(n_ch * n * 4)
+    for c in range(n_ch):       # independent streams: per-channel tone 300..3000 Hz, seed = base + channel
+        sdr_amd.capi.synth_fm_i16_dev(d_in.at(c * n * 4), n, fs=1.0e6, ftone=300.0 + 2700.0 * c / (n_ch - 1),
+                                      dev=5000.0, noise_lsb=2, seed=100 + c)
+    cnt = plan.out_count(n)
+    d_out = sdr_amd.DevBuf(n_ch * cnt * 4)
+    plan.execute_batched_dev(d_in, n, n, n_ch, d_out, cnt)
+    sdr_amd.sync()
+    worst = 0.0
+    for c in (0, 511, 1023):
+        iq = d_in.to_numpy(np.int16, 2 * n, c * n * 4)
+        want = O.chain_i16(iq, D, h, O.MODE_FM)
+        got = d_out.to_numpy(np.float32, cnt, c * cnt * 4).astype(np.float64)
+        worst = max(worst, float(np.abs(got - want).max()))
+    assert worst <= 5e-6, worst
+    ms = plan.time_dev(d_in, n, d_out, iters, in_stride=n, n_channels=n_ch, out_stride=cnt)
+    line("cfg3 channelizer 1024 x 2^20, 64 taps /10 FM", n_ch * n, ms, 4.0 + 4.0 / D,
+         {"parity_max_abs_err": worst, "kernel": plan.info()})
+
+
+def cfg4(iters):
+    n, nfft, hop = 1 << 28, 4096, 2048
+    w = sdr_amd.window("blackman", nfft)
+    plan = sdr_amd.FftPlan(nfft, hop, w)
+    d_in = sdr_amd.DevBuf(n * 4)
+    sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=61.44e6, ftone=250e3, dev=2.0e6, amp=1200.0, noise_lsb=64, seed=3)
+    frames = plan.frame_count(n)
+    d_out = sdr_amd.DevBuf(frames * nfft * 4)
+    assert plan.execute_dev(d_in, n, d_out, frames) == frames
+    sdr_amd.sync()
+    worst = 0.0
+    for f0 in (0, frames // 2, frames - 4):
+        iq = d_in.to_numpy(np.int16, 2 * (nfft + 3 * hop), f0 * hop * 4)
+        want_db, want_lin = O.fft_power_db_i16(iq, nfft, hop, w, linear=True)
+        got = d_out.to_numpy(np.float32, 4 * nfft, f0 * nfft * 4).reshape(4, nfft).astype(np.float64)
+        lin = 10.0 ** (got / 10.0)
+        worst = max(worst, float(np.abs(lin - want_lin).max() / want_lin.max()))
+    assert worst <= 1e-5, worst
+    ms = plan.time_dev(d_in, n, d_out, iters)
+    line("cfg4 waterfall 4096-pt Blackman FFT -> dB, hop 2048, 2^28 samples", n, ms, 12.0,
+         {"parity_max_rel_power_err": worst, "frames": frames})
+
+
+def cfg5(iters):
+    n, D1, D2, T = 1 << 26, 10, 15, 511
+    h1 = sdr_amd.create_fir_filter(T, 20800 / 62400.0 / 5, "hann")
+    h2 = sdr_amd.create_fir_filter(T, 2400 / 62400.0, "hann")
+    fr = 2400 / 62400.0
+    p1 = sdr_amd.FirPlan(h1, D1, mode=sdr_amd.MODE_FM)
+    p2 = sdr_amd.FirPlan(h2, D2, mode=sdr_amd.MODE_ENV, input=sdr_amd.IN_F32_REAL, mix_fr=fr)
+    d_in = sdr_amd.DevBuf(n * 4)
+    sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=624e3, ftone=2400.0, dev=17000.0, amp=1800.0, noise_lsb=4, seed=5)
+    n6 = p1.out_count(n)
+    n9 = p2.out_count(n6)
+    d_x6, d_x9 = sdr_amd.DevBuf(n6 * 4), sdr_amd.DevBuf(n9 * 4)
+    p1.execute_dev(d_in, n, d_x6, n6)
+    p2.execute_dev(d_x6, n6, d_x9, n9)
+    sdr_amd.sync()
+    m = 1 << 20                                     # parity on the first 2^20 samples (zero pre-history)
+    iq = d_in.to_numpy(np.int16, 2 * m)
+    w9, w6 = O.apt_chain_i16(iq, D1, h1, fr, D2, h2)
+    g6 = d_x6.to_numpy(np.float32, w6.size).astype(np.float64)
+    g9 = d_x9.to_numpy(np.float32, w9.size).astype(np.float64)
+    s6 = T // D1 + 2
+    s9 = s6 // D2 + 2 + T // D2
+    worst = max(float(np.abs(g6 - w6)[s6:].max()), float(np.abs(g9 - w9)[s9:-T // D2 - 2].max()))
+    assert worst <= 5e-6, worst
+    ms1 = p1.time_dev(d_in, n, d_x6, iters)
+    ms2 = p2.time_dev(d_x6, n6, d_x9, iters)
+    line("cfg5 APT 511 taps /10 FM -> mix -> 511 taps /15 envelope, 2^26 samples", n, ms1 + ms2,
+         4.0 + 4.0 / (D1 * D2), {"stage1_ms": round(ms1, 4), "stage2_ms": round(ms2, 4),
+                                 "fp32_flops_per_sample": round(4.0 * T / D1 + 4.0 * T / (D1 * D2), 1),
+                                 "achieved_tflops": round((4.0 * T / D1 + 4.0 * T / (D1 * D2)) * n / ((ms1 + ms2) * 1e-3) / 1e12, 2),
+                                 "parity_max_abs_err": worst, "stage1_kernel": p1.info(), "stage2_kernel": p2.info()})
+
+
+if __name__ == "__main__":
+    sdr_amd.init(0)
+    which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
+    for w in which:
+        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[w](10)

@@ -19,13 +19,14 @@
 // through scalar loads and cost no LDS or VALU work.
 //
 // Two kernels share that scheme:
-//   fir_stream_kernel  (the default) keeps FLOAT samples in LDS: persistent workgroups fetch the
-//       raw tile k+1 from HBM into registers while they walk tile k, then convert it ONCE per
-//       sample (int16 -> f32 is a half-rate VALU op on gfx950, and a sample is read by ~4 lanes),
-//       apply the optional NCO mixer, and write float2 to LDS.  Any input type.
-//   fir_raw_kernel     keeps the RAW int16 pairs in LDS, filled by LDS-DMA
-//       (global_load_lds_dwordx4, no VGPR round trip), and converts after each LDS read.  Half
-//       the LDS footprint; kept for shapes whose float tile does not fit (plan `pipeline` = 1).
+//   fir_raw_kernel     (automatic choice for int16 input without mixer) keeps the RAW int16 pairs
+//       in LDS, filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), and converts
+//       after each LDS read.  Half the LDS footprint: 6 workgroups per CU on the headline shape.
+//   fir_stream_kernel  keeps FLOAT samples in LDS: persistent workgroups fetch the raw tile k+1
+//       from HBM into registers while they walk tile k, then convert it ONCE per sample
+//       (int16 -> f32 is a half-rate VALU op on gfx950, and a sample is read by ~4 lanes), apply
+//       the optional NCO mixer, and write float2 to LDS.  Any input type; the choice for float
+//       inputs, the mixer, and shapes whose raw geometry does not fit (plan `pipeline` = 2).
 // Lane stride in LDS is q = D*R/(samples per 16 B) granules; when q is even the tile image
 // carries one pad granule per q (stride q+1, odd) so that ds_read_b128's 16-lane groups hit
 // distinct banks.

@@ -111,8 +111,30 @@ def cfg5(iters):
                                  "parity_max_abs_err": worst, "stage1_kernel": p1.info(), "stage2_kernel": p2.info()})
 
 
+def handoff(_iters):
+    """PCIe-inclusive rate of the streaming hand-off (host block in, host outputs back)."""
+    import time
+    nb, blk, D, T = 16, 1 << 24, 10, 64
+    h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
+    plan = sdr_amd.FirPlan(h, D, mode=sdr_amd.MODE_FM)
+    iq = O.synth_fm_i16(blk, fs=20e6, ftone=1000.0, dev=75e3)
+    st = sdr_amd.FirStream(plan, blk)
+    st.push(iq); st.pop()                           # warm-up (pinned pages, first launch)
+    t0 = time.perf_counter()
+    st.push(iq)
+    got = 0
+    for _ in range(nb - 1):
+        st.push(iq)
+        got += st.pop().size
+    got += st.pop().size
+    dt = time.perf_counter() - t0
+    print(json.dumps({"config": "hand-off: 16 host blocks of 2^24 samples through sdr_fir_stream (pinned staging, "
+                                "H2D, kernel, D2H), 64 taps /10 FM", "Msamples_per_s": round(nb * blk / dt / 1e6, 1),
+                      "host_GBps_in": round(nb * blk * 4 / dt / 1e9, 2), "outputs": got}), flush=True)
+
+
 if __name__ == "__main__":
     sdr_amd.init(0)
-    which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
+    which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5", "handoff"]
     for w in which:
-        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[w](10)
+        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5, "handoff": handoff}[w](10)

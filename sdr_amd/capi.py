@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdrhip.so")
+LIB_PATH = os.environ.get("SDRHIP_LIB") or os.path.join(_HERE, "libsdrhip.so")   # override: kernel experiments
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "stream.hip", "lib.hip")]
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
@@ -34,17 +34,34 @@ class FirDesc(C.Structure):
                 ("outputs_per_lane", C.c_int), ("threads", C.c_int), ("pipeline", C.c_int)]
 
 
+# per-file compiler flags: the FFT's complex butterflies lose ~12 % when the SLP vectoriser pairs
+# them into v_pk_add_f32 (same issue cost as two scalar adds on gfx950, plus the moves that build
+# the register pairs); the FIR walk gains from v_pk_fma_f32 and keeps the default
+EXTRA_FLAGS = {"fft.hip": ["-fno-slp-vectorize"]}
+
+
 def build(force=False):
     """hipcc -> sdr_amd/libsdrhip.so (cross-compiles for gfx950 without a GPU)."""
     srcs = [s for s in SOURCES if os.path.exists(s)]
     deps = srcs + [os.path.join(_HERE, "csrc", "sdr_internal.h"),
-                   os.path.join(INCLUDE, "sdr_hip.h")]
+                   os.path.join(INCLUDE, "sdr_hip.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-I" + os.path.join(_HERE, "csrc"), "-o", LIB_PATH] + srcs
-    subprocess.check_call(cmd)
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+            "-I" + INCLUDE, "-I" + os.path.join(_HERE, "csrc")]
+    objs, procs = [], []
+    for src in srcs:
+        name = os.path.basename(src)
+        obj = os.path.join(objdir, name.replace(".hip", ".o"))
+        objs.append(obj)
+        procs.append(subprocess.Popen(base + EXTRA_FLAGS.get(name, []) + ["-c", src, "-o", obj]))
+    for pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, pr.args)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 
@@ -166,7 +183,7 @@ class FirPlan:
         r, nt, lds = C.c_int(), C.c_int(), C.c_int()
         check(lib().sdr_fir_plan_info(self.h, C.byref(r), C.byref(nt), C.byref(lds)))
         return {"outputs_per_lane": r.value, "threads": nt.value, "lds_bytes": lds.value,
-                "kernel": {1: "raw_tile", 2: "stream"}.get(lib().sdr_fir_plan_kernel(self.h), "?")}
+                "kernel": {1: "raw_tile", 2: "stream", 3: "planar"}.get(lib().sdr_fir_plan_kernel(self.h), "?")}
 
     def out_count(self, n_in):
         return lib().sdr_fir_out_count(self.h, n_in)

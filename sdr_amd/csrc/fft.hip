@@ -106,80 +106,169 @@ __device__ __forceinline__ void dft<16>(float2 (&x)[16])
 
 __device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// would wait for the next frame's prefetched samples and the previous frame's dB stores at every
+// exchange; here only LDS (lgkmcnt) has to be complete.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct FftGeom {
     long long n_in;      // samples available
     long long frames;    // frames to compute
+    long long chunk;     // consecutive frames one (workgroup, slot) pair transforms
+    float *dummy;        // one spare row: slots past the last frame store there
     int hop;
 };
 
-// One Stockham pass on registers: inputs gathered from `lds` at j + t*N/R, twiddled by
-// W_{Ns*R}^{t*k} (k = j mod Ns), R-point DFT.  Natural-order bin of output t is
-// (j/Ns)*Ns*R + k + t*Ns.
+// twiddles of one Stockham pass for butterfly index j: W_{Ns*R}^{t*k}, k = j mod Ns, t = 1..R-1.
+// They depend on the lane only, so a persistent lane loads them once.
 template <int N, int R>
-__device__ __forceinline__ void pass_load(float2 (&x)[R], const float2 *lds, int j, int Ns,
-                                          const float2 *__restrict__ tw)
+__device__ __forceinline__ void pass_twiddles(float2 (&w)[R > 1 ? R - 1 : 1], int j, int Ns,
+                                              const float2 *__restrict__ tw)
 {
-#pragma unroll
-    for (int t = 0; t < R; ++t) x[t] = lds[pidx(j + t * (N / R))];
     const int k = j & (Ns - 1);
     const int step = N / (Ns * R);
 #pragma unroll
-    for (int t = 1; t < R; ++t) x[t] = cmul(x[t], tw[t * k * step]);
+    for (int t = 1; t < R; ++t) w[t - 1] = tw[t * k * step];
+}
+
+// One Stockham pass on registers: inputs gathered from `lds` at j + t*N/R, twiddled, R-point DFT.
+// Natural-order bin of output t is (j/Ns)*Ns*R + (j mod Ns) + t*Ns.
+template <int N, int R>
+__device__ __forceinline__ void pass_load(float2 (&x)[R], const float2 *lds, int j,
+                                          const float2 (&w)[R > 1 ? R - 1 : 1])
+{
+#pragma unroll
+    for (int t = 0; t < R; ++t) x[t] = lds[pidx(j + t * (N / R))];
+#pragma unroll
+    for (int t = 1; t < R; ++t) x[t] = cmul(x[t], w[t - 1]);
     dft<R>(x);
 }
 
+// 20*log10|X| = 10*log10(|X|^2) through the hardware log2 (v_log_f32, ~1 ulp): exact zero power
+// gives -inf like the reference's log10(0).
 template <int N>
 __device__ __forceinline__ void emit_db(float *__restrict__ row, int bin, float2 v)
 {
     const float p = __fmaf_rn(v.x, v.x, v.y * v.y);
-    row[(bin + N / 2) & (N - 1)] = 10.0f * log10f(p);
+    row[(bin + N / 2) & (N - 1)] = 3.01029995663981195f * __log2f(p);
 }
 
-// N = 16 * R2 * R3 (R3 == 1: two passes)
-template <int N, int R2, int R3>
-__global__ void __launch_bounds__(256)
+// N = 16 * R2 * R3 (R3 == 1: two passes).  HALF: hop == N/2, so the second half of a frame is the
+// first half of the next one and stays in the lane's registers (raw int16 pairs): every input
+// sample is fetched from HBM once.
+//
+// Persistent lanes: a workgroup holds FPB = 4096/N frame slots of N/16 lanes; each slot walks its
+// own run of `chunk` consecutive frames, so the per-lane constants (window values, twiddles of
+// both later passes) are loaded once, and the samples of frame k+1 are requested before frame k
+// is transformed.
+template <int N, int R2, int R3, bool HALF>
+#ifndef SDR_FFT_MINB
+#define SDR_FFT_MINB 3
+#endif
+__global__ void __launch_bounds__(256, SDR_FFT_MINB)
 fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
               const float2 *__restrict__ tw, float *__restrict__ out, const FftGeom g)
 {
     constexpr int TPF = N / 16;            // lanes per frame
-    constexpr int FPB = 256 / TPF;         // frames per workgroup
+    constexpr int FPB = 256 / TPF;         // frame slots per workgroup
     constexpr int FR_LDS = N + N / 16;     // padded float2 per frame
+    constexpr int NEW = HALF ? 8 : 16;     // samples a lane fetches per frame
+    constexpr int B2 = 16 / R2;            // pass-2 butterflies per lane
+    constexpr int Ns3 = 16 * R2;
+    constexpr int B3 = R3 > 1 ? 16 / R3 : 1;
+    constexpr int NT2 = 16 * (R2 - 1);     // pass-2 twiddle table: W_{16*R2}^{t*k}, k = 0..15, t = 1..R2-1
     __shared__ float2 smem[FPB * FR_LDS];
+    __shared__ float2 tw2[NT2];
+    __shared__ float lwin[N];              // window table (registers are the scarcer resource here)
 
     const int tid = threadIdx.x;
     const int fl = tid / TPF;              // frame slot in the workgroup
     const int tl = tid - fl * TPF;         // lane within the frame
-    const long long f = (long long)blockIdx.x * FPB + fl;
-    const bool live = f < g.frames;
     float2 *lds = smem + fl * FR_LDS;
-    float *row = out + f * N;
 
-    // ---- pass 1: radix 16 from HBM, Ns = 1 ------------------------------------------------
-    float2 x[16];
+    const long long f0 = ((long long)blockIdx.x * FPB + fl) * g.chunk;     // first frame of this slot
+    long long f_end = f0 + g.chunk;
+    if (f_end > g.frames) f_end = g.frames;
+
+    for (int i = tid; i < N; i += 256) lwin[i] = win[i];
+    // pass-2 twiddles depend on (j mod 16, t) only: one small table per workgroup in LDS; the
+    // pass-3 ones differ per lane and stay in registers
+    for (int i = tid; i < NT2; i += 256) {
+        const int k = i / (R2 - 1), t = i - k * (R2 - 1) + 1;
+        tw2[i] = tw[t * k * (N / (16 * R2))];
+    }
+    float2 w3[B3][R3 > 1 ? R3 - 1 : 1];
+    if constexpr (R3 > 1) {
+#pragma unroll
+        for (int i = 0; i < B3; ++i) pass_twiddles<N, R3>(w3[i], tl + i * TPF, Ns3, tw);
+    }
+
+    // raw samples: keep[] = those already in registers for the coming frame (HALF), nxt[] = fetched.
+    // Loads and stores are issued unconditionally (a slot past the last frame re-reads the last
+    // frame and stores to the spare row): with no branch around them hipcc can wait for the
+    // prefetch with a counted vmcnt instead of draining the previous frame's stores.
+    const long long last = g.frames - 1;
+    uint32_t keep[8], nxt[NEW];
     {
-        const uint32_t *src = iq + f * g.hop;
+        const uint32_t *src = iq + (f0 < last ? f0 : last) * g.hop;
+        if constexpr (HALF) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) keep[t] = src[tl + t * TPF];
+        }
+#pragma unroll
+        for (int t = 0; t < NEW; ++t) nxt[t] = src[tl + (t + 16 - NEW) * TPF];
+    }
+
+    // Sixteen stores after the first prefetch, as after every later one: the loop-top wait for the
+    // prefetched samples can then be the same counted vmcnt(16) on the entry edge and on the back
+    // edge (hipcc merges the two and would otherwise drain everything, stores included).
+#pragma unroll
+    for (int t = 0; t < 16; ++t) g.dummy[(tid + 256 * t) & (N - 1)] = 0.f;
+
+    __syncthreads();                       // tables filled
+    for (long long it = 0; it < g.chunk; ++it) {
+        const long long f = f0 + it;
+        const bool live = f < f_end;
+        // ---- pass 1: radix 16 on the raw samples, Ns = 1 ---------------------------------------
+        float2 x[16];
+        uint32_t raw[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) raw[t] = (t < 16 - NEW) ? keep[t % 8] : nxt[t - (16 - NEW)];
+        if constexpr (HALF) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) keep[t] = nxt[t];
+        }
+        {                                  // request the next frame's samples now
+            const uint32_t *src = iq + (f + 1 < last ? f + 1 : last) * g.hop;
+#pragma unroll
+            for (int t = 0; t < NEW; ++t) nxt[t] = src[tl + (t + 16 - NEW) * TPF];
+        }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const int idx = tl + t * TPF;
-            uint32_t w = 0;
-            if (live) w = src[idx];
-            const float wv = win[idx];
-            x[t] = make_float2((float)(short)(w & 0xffffu) * wv, (float)((int)w >> 16) * wv);
+            const float wv = lwin[tl + t * TPF];
+            x[t] = make_float2((float)(short)(raw[t] & 0xffffu) * wv, (float)((int)raw[t] >> 16) * wv);
         }
         dft<16>(x);
 #pragma unroll
         for (int t = 0; t < 16; ++t) lds[pidx(tl * 16 + t)] = x[t];
-    }
-    __syncthreads();
+        lds_barrier();  
 
-    // ---- pass 2: radix R2, Ns = 16 ----------------------------------------------------------
-    constexpr int B2 = 16 / R2;            // butterflies per lane
-    float2 y[B2][R2];
+        float *row = live ? out + f * N : g.dummy;
+        // ---- pass 2: radix R2, Ns = 16 ------------------------------------------------------
+        float2 y[B2][R2];
 #pragma unroll
-    for (int i = 0; i < B2; ++i) pass_load<N, R2>(y[i], lds, tl + i * TPF, 16, tw);
+        for (int i = 0; i < B2; ++i) {
+            const int j = tl + i * TPF;
+            float2 w2[R2 - 1];
+#pragma unroll
+            for (int t = 0; t < R2 - 1; ++t) w2[t] = tw2[(j & 15) * (R2 - 1) + t];
+            pass_load<N, R2>(y[i], lds, j, w2);
+        }
 
-    if constexpr (R3 == 1) {
-        if (live) {
+        if constexpr (R3 == 1) {
 #pragma unroll
             for (int i = 0; i < B2; ++i) {
                 const int j = tl + i * TPF;
@@ -187,30 +276,28 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
 #pragma unroll
                 for (int t = 0; t < R2; ++t) emit_db<N>(row, base + t * 16, y[i][t]);
             }
-        }
-    } else {
-        __syncthreads();                   // every lane has gathered its pass-2 inputs
+            lds_barrier();                 // the slot's image is free for the next frame
+        } else {
+            lds_barrier();                 // every lane has gathered its pass-2 inputs
 #pragma unroll
-        for (int i = 0; i < B2; ++i) {
-            const int j = tl + i * TPF;
-            const int base = (j >> 4) * (16 * R2) + (j & 15);
+            for (int i = 0; i < B2; ++i) {
+                const int j = tl + i * TPF;
+                const int base = (j >> 4) * (16 * R2) + (j & 15);
 #pragma unroll
-            for (int t = 0; t < R2; ++t) lds[pidx(base + t * 16)] = y[i][t];
-        }
-        __syncthreads();
-        // ---- pass 3: radix R3, Ns = 16*R2 -------------------------------------------------
-        constexpr int Ns3 = 16 * R2;
-        constexpr int B3 = 16 / R3;
+                for (int t = 0; t < R2; ++t) lds[pidx(base + t * 16)] = y[i][t];
+            }
+            lds_barrier();  
+            // ---- pass 3: radix R3, Ns = 16*R2 ---------------------------------------------
 #pragma unroll
-        for (int i = 0; i < B3; ++i) {
-            float2 z[R3];
-            const int j = tl + i * TPF;
-            pass_load<N, R3>(z, lds, j, Ns3, tw);
-            if (live) {
+            for (int i = 0; i < B3; ++i) {
+                float2 z[R3];
+                const int j = tl + i * TPF;
+                pass_load<N, R3>(z, lds, j, w3[i]);
                 const int base = (j / Ns3) * (Ns3 * R3) + (j & (Ns3 - 1));
 #pragma unroll
                 for (int t = 0; t < R3; ++t) emit_db<N>(row, base + t * Ns3, z[t]);
             }
+            lds_barrier();                 // the slot's image is free for the next frame
         }
     }
 }
@@ -219,8 +306,10 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
 
 struct sdr_fft_plan {
     int nfft, hop;
+    int n_cu = 256;
     float *d_win = nullptr;
     float2 *d_tw = nullptr;
+    float *d_dummy = nullptr;
     void *d_in = nullptr, *d_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
 };
@@ -239,22 +328,33 @@ int launch_fft(sdr_fft_plan *p, const int16_t *d_iq, long long n_in, float *d_ou
     if (frames == 0) return SDR_OK;
     if (((uintptr_t)d_iq) & 3 || ((uintptr_t)d_out) & 3) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
     FftGeom g;
-    g.n_in = n_in; g.frames = frames; g.hop = p->hop;
+    g.n_in = n_in; g.frames = frames; g.hop = p->hop; g.dummy = p->d_dummy;
     const int fpb = 256 / (p->nfft / 16);
-    const long long blocks = (frames + fpb - 1) / fpb;
-    if (blocks > 0x7fffffffLL) { sdr::set_error("too many frames"); return SDR_EINVAL; }
+    // persistent grid: the resident workgroups of every CU; every (workgroup, slot) pair gets one run of
+    // `chunk` consecutive frames
+    long long groups = (long long)p->n_cu * SDR_FFT_MINB * fpb;
+    if (groups > frames) groups = frames;
+    g.chunk = (frames + groups - 1) / groups;
+    const long long blocks = ((frames + g.chunk - 1) / g.chunk + fpb - 1) / fpb;
     const uint32_t *in = (const uint32_t *)d_iq;
     dim3 grid((unsigned)blocks);
+    const bool half = (p->hop * 2 == p->nfft);
+#define SDR_FFT(N, R2, R3)                                                                        \
+    do {                                                                                          \
+        if (half) fft_db_kernel<N, R2, R3, true><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); \
+        else fft_db_kernel<N, R2, R3, false><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g);     \
+    } while (0)
     switch (p->nfft) {
-    case 4096: fft_db_kernel<4096, 16, 16><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); break;
-    case 2048: fft_db_kernel<2048, 16, 8><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); break;
-    case 1024: fft_db_kernel<1024, 16, 4><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); break;
-    case 512: fft_db_kernel<512, 8, 4><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); break;
-    case 256: fft_db_kernel<256, 16, 1><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); break;
-    case 128: fft_db_kernel<128, 8, 1><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); break;
-    case 64: fft_db_kernel<64, 4, 1><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); break;
+    case 4096: SDR_FFT(4096, 16, 16); break;
+    case 2048: SDR_FFT(2048, 16, 8); break;
+    case 1024: SDR_FFT(1024, 16, 4); break;
+    case 512: SDR_FFT(512, 8, 4); break;
+    case 256: SDR_FFT(256, 16, 1); break;
+    case 128: SDR_FFT(128, 8, 1); break;
+    case 64: SDR_FFT(64, 4, 1); break;
     default: sdr::set_error("unsupported nfft %d", p->nfft); return SDR_EINVAL;
     }
+#undef SDR_FFT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sdr::hip_fail(e, "fft kernel launch");
     return SDR_OK;
@@ -272,6 +372,12 @@ extern "C" int sdr_fft_plan_create(int nfft, int hop, const double *window, sdr_
     if (rc != SDR_OK) return rc;
     sdr_fft_plan *p = new sdr_fft_plan();
     p->nfft = nfft; p->hop = hop;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            p->n_cu = prop.multiProcessorCount;
+    }
     // window table carries the Q11 scale and the 1/N of fftInPlace(x, 1/N): both powers of two
     std::vector<float> w(nfft);
     const double s = 1.0 / (2048.0 * (double)nfft);
@@ -283,6 +389,7 @@ extern "C" int sdr_fft_plan_create(int nfft, int hop, const double *window, sdr_
     }
     hipError_t e = hipMalloc((void **)&p->d_win, sizeof(float) * nfft);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw, sizeof(float2) * nfft);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_dummy, sizeof(float) * nfft);
     if (e == hipSuccess) e = hipMemcpy(p->d_win, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * nfft, hipMemcpyHostToDevice);
     if (e != hipSuccess) { sdr_fft_plan_destroy(p); return sdr::hip_fail(e, "fft plan upload"); }
@@ -295,6 +402,7 @@ extern "C" int sdr_fft_plan_destroy(sdr_fft_plan *p)
     if (!p) return SDR_OK;
     if (p->d_win) (void)hipFree(p->d_win);
     if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_dummy) (void)hipFree(p->d_dummy);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     delete p;

@@ -565,6 +565,181 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     store_outputs<R>(g, outv, ch, m0, acc, ynext);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fir_planar_kernel: int16 IQ without mixer, converted ONCE while the tile is staged and kept as
+// two float planes (all I, all Q) in LDS.  On gfx950 only plain f32 FMA/MUL/ADD issue in 2 cycles
+// per wave64; v_cvt_f32_i32 (and every packed, SDWA or DPP form) takes 4, and in the raw-tile
+// kernel each sample is converted by every lane whose window covers it (~4 for 64 taps / 10).
+// Here a sample is converted by the one lane that stages it and the walk is FMA only.  Planes
+// rather than interleaved float2: the lane stride stays D*R*4 bytes, the same bank pattern (and
+// the same granule geometry, 4 samples per 16 B) as the raw tile, at twice the LDS footprint.
+// LDS: [I plane (a_gran float4) | Q plane (a_gran float4) | ybuf (NT+2 float2)].
+// ---------------------------------------------------------------------------------------------
+template <int U, bool PAD>
+__device__ __forceinline__ void pwalk_load(float4 (&vr)[U], float4 (&vi)[U], const float4 *re,
+                                           const float4 *im, int c, const FirGeom &g)
+{
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int idx = walk_index<PAD>(c + k, g);
+        vr[k] = re[idx];
+        vi[k] = im[idx];
+    }
+}
+
+template <int U, int N>
+__device__ __forceinline__ void pwalk_touch(const float4 (&vr)[U], const float4 (&vi)[U],
+                                            const float (&t)[N])
+{
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        asm volatile("" ::"v"(vr[k].x), "v"(vr[k].y), "v"(vr[k].z), "v"(vr[k].w));
+        asm volatile("" ::"v"(vi[k].x), "v"(vi[k].y), "v"(vi[k].z), "v"(vi[k].w));
+    }
+#pragma unroll
+    for (int k = 0; k < N; k += 8)
+        asm volatile("" ::"s"(t[k]), "s"(t[k + 1]), "s"(t[k + 2]), "s"(t[k + 3]), "s"(t[k + 4]),
+                     "s"(t[k + 5]), "s"(t[k + 6]), "s"(t[k + 7]));
+}
+
+template <int R, int U>
+__device__ __forceinline__ void pwalk_fma(const float4 (&vr)[U], const float4 (&vi)[U],
+                                          const float (&t)[4 * R * U], float (&ar)[R], float (&ai)[R])
+{
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const float xi[4] = {vr[k].x, vr[k].y, vr[k].z, vr[k].w};
+        const float xq[4] = {vi[k].x, vi[k].y, vi[k].z, vi[k].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float h = t[(k * 4 + u) * R + r];
+                ar[r] = __fmaf_rn(h, xi[u], ar[r]);
+                ai[r] = __fmaf_rn(h, xq[u], ai[r]);
+            }
+    }
+}
+
+template <int R, bool PAD>
+__device__ __forceinline__ void pwalk_p(const FirGeom &g, const float4 *re4, const float4 *im4,
+                                        const float *__restrict__ gtab, int tid, float2 (&acc)[R])
+{
+    constexpr int U = Walk<4, R>::U;
+    constexpr int N = Walk<4, R>::N;
+    float ar[R], ai[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ar[r] = 0.f; ai[r] = 0.f; }
+    const int lane_off = tid * (g.q + (PAD ? 1 : 0));
+    const float4 *re = re4 + lane_off, *im = im4 + lane_off;
+    const int nstep = g.ngran / U;           // even (host pads)
+    float4 var[U], vai[U], vbr[U], vbi[U];
+    float ta[N], tb[N];
+    pwalk_load<U, PAD>(var, vai, re, im, 0, g);
+    walk_taps<N>(ta, gtab);
+    for (int s = 0; s < nstep; s += 2) {
+        pwalk_touch<U, N>(var, vai, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        pwalk_load<U, PAD>(vbr, vbi, re, im, (s + 1) * U, g);
+        walk_taps<N>(tb, gtab + (size_t)(s + 1) * N);
+        __builtin_amdgcn_sched_barrier(0);
+        pwalk_fma<R, U>(var, vai, ta, ar, ai);
+        pwalk_touch<U, N>(vbr, vbi, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        pwalk_load<U, PAD>(var, vai, re, im, (s + 2) * U, g);      // look-ahead step (zero taps at the end)
+        walk_taps<N>(ta, gtab + (size_t)(s + 2) * N);
+        __builtin_amdgcn_sched_barrier(0);
+        pwalk_fma<R, U>(vbr, vbi, tb, ar, ai);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float2(ar[r], ai[r]);
+}
+
+__device__ __forceinline__ float2 successor_planar(const FirGeom &g, const float *re, const float *im,
+                                                   const float *taps, int tid, int NT, int R)
+{
+    float2 part = make_float2(0.f, 0.f);
+    const int sbase = g.D * NT * R + g.Tback;          // window offset of sample D*(M0+NT*R)
+    for (int i = tid; i < g.T; i += 64) {
+        const int sidx = sbase - i;
+        const int at = lds_granule(g, sidx >> 2) * 4 + (sidx & 3);
+        const float h = taps[i];
+        part.x = __fmaf_rn(h, re[at], part.x);
+        part.y = __fmaf_rn(h, im[at], part.y);
+    }
+    return wave_sum(part);
+}
+
+constexpr int kPlanarSlots = 8;     // granules one lane stages per round of loads
+
+template <int R>
+__global__ void __launch_bounds__(256)
+fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
+                  const float *__restrict__ gtab, const float *__restrict__ taps, const FirGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *re4 = (float4 *)smem;
+    float4 *im4 = re4 + g.a_gran;
+    const int tid = threadIdx.x;
+    const int NT = blockDim.x;
+    const long long ch = blockIdx.y;
+    const long long M0 = g.tile0 + (long long)blockIdx.x * (NT * R);
+    const long long W0 = M0 * g.D - g.Tback;                 // first staged sample (multiple of 4)
+    const uint32_t *src = in + ch * g.in_stride;             // sample 0 of this channel
+
+    const bool interior = (W0 >= g.lo_valid) && (W0 + 4LL * g.s_gran <= g.hi_valid);
+    for (int k0 = 0; k0 < g.n_inst; k0 += kPlanarSlots) {
+        uint4 w[kPlanarSlots];
+        // all loads of the round first, unconditionally (slots past the tile repeat its last
+        // round-robin row: a branch per load would serialise the HBM round trips)
+#pragma unroll
+        for (int k = 0; k < kPlanarSlots; ++k) {
+            const int kk = (k0 + k < g.n_inst) ? k0 + k : g.n_inst - 1;
+            int sg = sample_granule(g, kk * NT + tid);
+            sg = sg < g.s_gran ? sg : 0;
+            const long long s = W0 + 4LL * sg;
+            if (interior) {
+                w[k] = *(const uint4 *)(src + s);
+            } else {
+                uint32_t e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long si = s + u;
+                    e[u] = (si >= g.lo_valid && si < g.hi_valid) ? src[si] : 0u;
+                }
+                w[k] = make_uint4(e[0], e[1], e[2], e[3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPlanarSlots; ++k) {
+            if (k0 + k < g.n_inst) {
+                const int a = (k0 + k) * NT + tid;
+                re4[a] = make_float4(lo16(w[k].x), lo16(w[k].y), lo16(w[k].z), lo16(w[k].w));
+                im4[a] = make_float4(hi16(w[k].x), hi16(w[k].y), hi16(w[k].z), hi16(w[k].w));
+            }
+        }
+    }
+    __syncthreads();
+
+    float2 acc[R];
+    if (g.pad) pwalk_p<R, true>(g, re4, im4, gtab, tid, acc);
+    else pwalk_p<R, false>(g, re4, im4, gtab, tid, acc);
+
+    const long long m0 = M0 + (long long)tid * R;
+    float2 ynext = make_float2(0.f, 0.f);
+    if (g.mode == SDR_MODE_FM) {
+        float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 32);
+        ybuf[tid] = acc[0];
+        if (tid < 64) {
+            const float2 ys = successor_planar(g, (const float *)re4, (const float *)im4, taps, tid, NT, R);
+            if (tid == 0) ybuf[NT] = ys;
+        }
+        __syncthreads();
+        ynext = ybuf[tid + 1];
+    }
+    store_outputs<R>(g, outv, ch, m0, acc, ynext);
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -572,7 +747,8 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 // =============================================================================================
 struct sdr_fir_plan {
     int input, mode, D, T, R, NT;
-    bool raw;               // fir_raw_kernel (else fir_stream_kernel)
+    bool raw;               // raw-tile geometry (4 samples per granule): fir_raw_kernel or fir_planar_kernel
+    bool planar = false;    // fir_planar_kernel (float planes, convert once)
     double scale, mix_fr;
     int spg;                // samples per LDS granule: 4 (raw) / 2 (stream)
     int Tback, Lw4, ngran, q, pad, s_gran, a_gran, n_inst, lds_bytes;
@@ -592,7 +768,7 @@ struct Geometry { int Tback, Lw4, U, ngran, look, q, pad, s_gran, a_gran, n_inst
 
 // Tile geometry for (T, D, R, NT) with spg samples per LDS granule.  Returns false when the lane
 // stride is not a whole number of granules.
-bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *o)
+bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *o, bool planar = false)
 {
     if (((long long)D * R) % spg) return false;
     o->Tback = roundup(T - 1, 4);
@@ -611,7 +787,7 @@ bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *
     const int a = o->s_gran + (o->pad ? o->s_gran / o->q + 1 : 0);
     o->a_gran = roundup(a, NT);
     o->n_inst = o->a_gran / NT;
-    o->lds_bytes = o->a_gran * 16 + (NT + 2) * 8 + (stream ? roundup(T, 4) * 4 : 0);
+    o->lds_bytes = o->a_gran * (planar ? 32 : 16) + (NT + 2) * 8 + (stream ? roundup(T, 4) * 4 : 0);
     return true;
 }
 
@@ -622,6 +798,14 @@ template <int R>
 hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void *out,
                     const FirGeom &g, unsigned tiles, unsigned n_ch)
 {
+    if (p->planar) {
+        if (p->lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)fir_planar_kernel<R>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+        fir_planar_kernel<R><<<dim3(tiles, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
+                                                                           p->d_gtab, p->d_taps, g);
+        return hipGetLastError();
+    }
     if (p->raw) {
         if (p->lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)fir_raw_kernel<R>,
@@ -708,7 +892,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->n_taps > 16384) { sdr::set_error("n_taps > 16384 unsupported"); return SDR_EINVAL; }
     if (d->input < SDR_IN_I16_IQ || d->input > SDR_IN_F32_REAL) { sdr::set_error("bad input kind"); return SDR_EINVAL; }
     if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_ENV) { sdr::set_error("bad mode"); return SDR_EINVAL; }
-    if (d->pipeline < 0 || d->pipeline > 2) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
+    if (d->pipeline < 0 || d->pipeline > 3) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
 
@@ -717,7 +901,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     p->scale = d->scale; p->mix_fr = d->mix_fr;
     (void)hipGetDevice(&p->device);
     const bool raw_possible = (d->input == SDR_IN_I16_IQ && d->mix_fr == 0.0);
-    if (d->pipeline == 1 && !raw_possible) { delete p; sdr::set_error("pipeline 1 needs int16 input without mixer"); return SDR_EINVAL; }
+    if ((d->pipeline == 1 || d->pipeline == 3) && !raw_possible) { delete p; sdr::set_error("pipeline 1 and 3 need int16 input without mixer"); return SDR_EINVAL; }
+    const bool planar = (d->pipeline == 3);
 
     // ---- choose kernel, outputs per lane (R) and workgroup size (NT) ------------------------
     // cost model (SIMD cycles per output, gfx950 measured issue costs: v_pk_fma_f32 4 cycles per
@@ -736,7 +921,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     for (int pass = 0; pass < 2 && !bestR; ++pass) {
         const bool raw = (pass == 0) ? raw_possible : !raw_possible;
         if (raw && (!raw_possible || d->pipeline == 2)) continue;
-        if (!raw && d->pipeline == 1) continue;
+        if (!raw && (d->pipeline == 1 || d->pipeline == 3)) continue;
         const int spg = raw ? 4 : 2;
         for (int ri = 0; ri < 4; ++ri) {
             const int R = Rs[ri];
@@ -745,11 +930,11 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 const int NT = NTs[ni];
                 if (d->threads && d->threads != NT) continue;
                 Geometry gm;
-                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm)) break;
+                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, raw && planar)) break;
                 if (!raw && gm.n_inst > kSlots) continue;
                 const bool forced = d->threads != 0;
                 // automatic choice: raw tiles <= 27 KB (6 workgroups per CU), float tiles <= 53 KB (3)
-                const int budget = (forced || ni == 2) ? 160 * 1024 : (raw ? 27 : 53) * 1024;
+                const int budget = (forced || ni == 2) ? 160 * 1024 : ((raw && !planar) ? 27 : 53) * 1024;
                 if (gm.lds_bytes > budget) continue;
                 // SIMD cycles per output (gfx950: v_pk_fma_f32 and v_cvt_f32_i32 issue in 4 cycles):
                 // one packed FMA per (sample, output), two conversions per sample read (raw only),
@@ -769,7 +954,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                        d->decim, d->n_taps, d->outputs_per_lane, d->threads, d->pipeline);
         return SDR_EINVAL;
     }
-    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->spg = best_raw ? 4 : 2;
+    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar; p->spg = best_raw ? 4 : 2;
     p->Tback = best.Tback; p->Lw4 = best.Lw4; p->ngran = best.ngran; p->q = best.q; p->pad = best.pad;
     p->s_gran = best.s_gran; p->a_gran = best.a_gran; p->n_inst = best.n_inst; p->lds_bytes = best.lds_bytes;
     {
@@ -847,7 +1032,7 @@ extern "C" int sdr_fir_plan_shape(const sdr_fir_plan *p, int *input, int *mode, 
 
 extern "C" int sdr_fir_plan_kernel(const sdr_fir_plan *p)
 {
-    return p ? (p->raw ? 1 : 2) : 0;
+    return p ? (p->planar ? 3 : (p->raw ? 1 : 2)) : 0;
 }
 
 extern "C" int sdr_fir_execute_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, void *d_out,

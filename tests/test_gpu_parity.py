@@ -176,14 +176,14 @@ def test_geometries_against_oracle(sdr, oracle, T, D):
     ran = 0
     for R in (1, 2, 4, 8):
         for NT in (64, 128, 256):
-            for pipe in (1, 2):      # one tile per workgroup / persistent double-buffered
+            for pipe in (1, 2, 3):   # raw tile / persistent float tiles / planar float tile
                 try:
                     p_fm = sdr.FirPlan(h, D, mode=sdr.MODE_FM, outputs_per_lane=R, threads=NT,
                                        pipeline=pipe)
                 except sdr.SdrError as e:
                     assert e.status == sdr.capi.EINVAL   # geometry not available (alignment / LDS)
                     continue
-                if pipe == 2 and p_fm.info()["lds_bytes"] > 160 * 1024:
+                if pipe >= 2 and p_fm.info()["lds_bytes"] > 160 * 1024:
                     continue
                 ran += 1
                 tag = f"T={T} D={D} R={R} NT={NT} pipe={pipe}"

@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/pmc_$tag
 mkdir -p $OUT
 pass() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 tools/run_one.py $ARGS > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; return 1; }
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 ${RUNNER:-tools/run_one.py} $ARGS > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; return 1; }
 }
 ARGS="$*"
 pass a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY || exit 1
@@ -19,7 +19,7 @@ import csv,glob,collections
 for f in sorted(glob.glob("$OUT/*/*/*_counter_collection.csv")):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "fir_" in r["Kernel_Name"]:
+        if "fir_" in r["Kernel_Name"] or "fft_" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in agg.items(): print(f"{k:28s} {sum(v)/len(v):16.0f}  (n={len(v)})")
 PY

@@ -15,5 +15,6 @@ sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=20e6, noise_lsb=8)
 d_out = sdr_amd.DevBuf(n + 64)
 h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
 p = sdr_amd.FirPlan(h, D, mode=mode, outputs_per_lane=R, threads=NT, pipeline=pipe)
-ms = p.time_dev(d_in, n, d_out, iters)
+p.time_dev(d_in, n, d_out, 40)          # clocks ramp over the first ~20 launches after idle
+ms = min(p.time_dev(d_in, n, d_out, iters) for _ in range(3))
 print("ms", ms, p.info())

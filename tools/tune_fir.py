@@ -30,12 +30,12 @@ def main():
         bps = 4.0 + (8.0 if mode == 0 else 4.0) / D
         for R in (1, 2, 4, 8):
             for NT in (64, 128, 256):
-                for pipe in (1, 2):
+                for pipe in [int(x) for x in os.environ.get('PIPES', '1,2,3').split(',')]:
                     try:
                         p = sdr_amd.FirPlan(h, D, mode=mode, outputs_per_lane=R, threads=NT, pipeline=pipe)
                     except sdr_amd.SdrError:
                         continue
-                    if pipe == 2 and p.info()['lds_bytes'] > 160 * 1024:
+                    if pipe >= 2 and p.info()['lds_bytes'] > 160 * 1024:
                         continue
                     p.time_dev(d_in, n, d_out, 2)
                     ms = p.time_dev(d_in, n, d_out, 10)

@@ -905,24 +905,42 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     const bool planar = (d->pipeline == 3);
 
     // ---- choose kernel, outputs per lane (R) and workgroup size (NT) ------------------------
-    // cost model (SIMD cycles per output, gfx950 measured issue costs: v_pk_fma_f32 4 cycles per
-    // two MACs, v_cvt_f32_i32 4 cycles): stream = FMAs only (conversion amortised over the tile),
-    // raw = FMAs + two conversions per sample read; plus the LDS read of the window per output.
+    // Raw-tile / planar kernels (int16, no mixer), from geometry sweeps on MI355X
+    // (tools/tune_fir.py; D = 2..20, T = 32..511): two outputs per lane halve the conversions per
+    // output and stay at an odd lane stride for most D; four when D is small (a lane should own
+    // >= 16 input samples); one or eight are never the best (one: a conversion pair per MAC pair;
+    // eight: 2-3x slower, tap SGPR sets and accumulators crowd the wave).  The largest workgroup
+    // whose tile leaves two workgroups per CU wins within an R.
+    // The streaming kernel (float inputs, mixer) keeps the instruction-count model below.
     const int Rs[4] = {1, 2, 4, 8};
     const int NTs[3] = {256, 128, 64};
     Geometry best{};
     int bestR = 0, bestNT = 0;
     bool best_raw = false;
     double best_cost = 0;
-    // Kernel kinds in order of preference: measured on MI355X the raw-tile kernel is the faster one
-    // for int16 input (6 resident workgroups per CU instead of 3), so the
-    // streaming kernel is the automatic choice only for the inputs the raw kernel cannot take
-    // or when no raw geometry fits.
-    for (int pass = 0; pass < 2 && !bestR; ++pass) {
-        const bool raw = (pass == 0) ? raw_possible : !raw_possible;
-        if (raw && (!raw_possible || d->pipeline == 2)) continue;
-        if (!raw && (d->pipeline == 1 || d->pipeline == 3)) continue;
-        const int spg = raw ? 4 : 2;
+    if (raw_possible && d->pipeline != 2) {
+        const int pref_small[4] = {4, 2, 1, 8}, pref_large[4] = {2, 4, 1, 8};
+        const int *pref = (p->D * 2 >= 16) ? pref_large : pref_small;
+        for (int ri = 0; ri < 4 && !bestR; ++ri) {
+            const int R = pref[ri];
+            if (d->outputs_per_lane && d->outputs_per_lane != R) continue;
+            for (int ni = 0; ni < 3; ++ni) {
+                const int NT = NTs[ni];
+                if (d->threads && d->threads != NT) continue;
+                Geometry gm;
+                if (!make_geometry(p->T, p->D, R, NT, 4, false, &gm, planar)) break;
+                const bool forced = d->threads != 0;
+                const int budget = (forced || ni == 2) ? 160 * 1024 : 56 * 1024;
+                if (gm.lds_bytes > budget) continue;
+                best = gm; bestR = R; bestNT = NT; best_raw = true;
+                break;
+            }
+        }
+    }
+    for (int pass = 0; pass < 1 && !bestR; ++pass) {
+        if (d->pipeline == 1 || d->pipeline == 3) continue;
+        const bool raw = false;
+        const int spg = 2;
         for (int ri = 0; ri < 4; ++ri) {
             const int R = Rs[ri];
             if (d->outputs_per_lane && d->outputs_per_lane != R) continue;
@@ -930,19 +948,19 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 const int NT = NTs[ni];
                 if (d->threads && d->threads != NT) continue;
                 Geometry gm;
-                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, raw && planar)) break;
-                if (!raw && gm.n_inst > kSlots) continue;
+                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false)) break;
+                if (gm.n_inst > kSlots) continue;
                 const bool forced = d->threads != 0;
-                // automatic choice: raw tiles <= 27 KB (6 workgroups per CU), float tiles <= 53 KB (3)
-                const int budget = (forced || ni == 2) ? 160 * 1024 : ((raw && !planar) ? 27 : 53) * 1024;
+                // automatic choice: float tiles <= 53 KB (3 workgroups per CU)
+                const int budget = (forced || ni == 2) ? 160 * 1024 : 53 * 1024;
                 if (gm.lds_bytes > budget) continue;
-                // SIMD cycles per output (gfx950: v_pk_fma_f32 and v_cvt_f32_i32 issue in 4 cycles):
-                // one packed FMA per (sample, output), two conversions per sample read (raw only),
-                // one ds_read_b128 per granule
+                // SIMD cycles per output: one packed FMA per (sample, output), one ds_read_b128
+                // per granule
                 const double walked = (double)gm.ngran * spg;                  // samples per lane
-                double cost = walked * (4.0 + (raw ? 8.0 : 0.0) / R) + walked / spg * 4.0 / R;
+                double cost = walked * 4.0 + walked / spg * 4.0 / R;
                 if (gm.pad) cost *= 1.1;                                       // padded image: extra index work
                 if (ni > 0) cost *= 1.05;                                      // smaller tiles: more halo
+                if (R == 8) cost *= 2.0;
                 if (!bestR || cost < best_cost) { best = gm; bestR = R; bestNT = NT; best_raw = raw; best_cost = cost; }
                 break;
             }

@@ -54,7 +54,12 @@ enum sdr_mode {
 enum sdr_input {
     SDR_IN_I16_IQ = 0,  /* interleaved int16 I,Q; the 1/2048 Q11 scale is applied            */
     SDR_IN_CF32 = 1,    /* interleaved float32 re,im (already scaled)                         */
-    SDR_IN_F32_REAL = 2 /* float32 real (e.g. the discriminator output fed to APT stage 2)    */
+    SDR_IN_F32_REAL = 2,/* float32 real (e.g. the discriminator output fed to APT stage 2)    */
+    SDR_IN_I16_QI = 3,  /* interleaved int16 Q,I (the "Q16 I16" wire order the B205 example
+                           records, b205_mini/rx_example/src/b205m_rx_main.cpp:54,210); Q11 scale   */
+    SDR_IN_I8_IQ = 4    /* interleaved int8 I,Q (HackRF transfer buffers,
+                           hackrf/rx_example/src/hackrf_rx_main.cpp:28,54; written as (int8_t) pairs
+                           in hackrf/tx_example/src/hackrf_tx_main.cpp:150-151); scale 1/128        */
 };
 
 enum sdr_window_id {

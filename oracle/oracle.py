@@ -110,6 +110,22 @@ def unpack_scale_i16(iq):
     return out.view(np.complex128)
 
 
+def unpack_scale_i16_qi(qi):
+    qi = _i16(qi)
+    n = qi.size // 2
+    out = np.empty(2 * n, np.float64)
+    lib().orc_unpack_scale_i16_qi(_s(qi), C.c_size_t(n), _d(out))
+    return out.view(np.complex128)
+
+
+def unpack_scale_i8(iq):
+    iq = np.ascontiguousarray(iq, dtype=np.int8).reshape(-1)
+    n = iq.size // 2
+    out = np.empty(2 * n, np.float64)
+    lib().orc_unpack_scale_i8(iq.ctypes.data_as(C.c_void_p), C.c_size_t(n), _d(out))
+    return out.view(np.complex128)
+
+
 def polyphase_decimate(x, D, h):
     """Reference semantics incl. the T % D restriction (raises ValueError like
     std::invalid_argument)."""

@@ -49,6 +49,27 @@ void orc_unpack_scale_i16(const int16_t *iq, size_t n, double *out)
     }
 }
 
+/* SURVEY 8(f2) wire formats.  Q-first int16 ("Q16 I16", b205_mini/rx_example/src/b205m_rx_main.cpp:54;
+ * written by write_qi_data, :210): the pair is (Q, I), same Q11 scale.  The reader/writer
+ * themselves live in the un-vendored Common repository (iq_utils.h): layout only, parity unpinned. */
+void orc_unpack_scale_i16_qi(const int16_t *qi, size_t n, double *out)
+{
+    const double s = 1.0 / 2048.0;
+    for (size_t j = 0; j < n; ++j) {
+        out[2 * j + 0] = (double)qi[2 * j + 1] * s;
+        out[2 * j + 1] = (double)qi[2 * j + 0] * s;
+    }
+}
+
+/* HackRF transfer buffers: interleaved int8 I, Q (hackrf/rx_example/src/hackrf_rx_main.cpp:28,54;
+ * the TX example fills them with (int8_t)real, (int8_t)imag, hackrf_tx_main.cpp:150-151).  The
+ * reference never scales them; full scale 128 -> 1/128 is this build's documented choice. */
+void orc_unpack_scale_i8(const int8_t *iq, size_t n, double *out)
+{
+    const double s = 1.0 / 128.0;
+    for (size_t j = 0; j < 2 * n; ++j) out[j] = (double)iq[j] * s;
+}
+
 /* float flavour of the same loop (bladerf_sdr.h:288-291): exact, power-of-two scale. */
 void orc_unpack_scale_i16_f32(const int16_t *iq, size_t n, float *out)
 {

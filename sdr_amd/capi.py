@@ -17,7 +17,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 OK, EINVAL, ENOMEM, EHIP, EALIGN, ECAPACITY, ENODEV, ERANGE = range(8)
 MODE_IQ, MODE_FM, MODE_ENV = 0, 1, 2
-IN_I16_IQ, IN_CF32, IN_F32_REAL = 0, 1, 2
+IN_I16_IQ, IN_CF32, IN_F32_REAL, IN_I16_QI, IN_I8_IQ = 0, 1, 2, 3, 4
 WINDOWS = {"rectangular": 0, "hann": 1, "hamming": 2, "blackman": 3, "nuttall": 4,
            "blackman_harris": 5}
 
@@ -193,8 +193,11 @@ class FirPlan:
         return np.complex64 if self.mode == MODE_IQ else np.float32
 
     def _in_array(self, x):
-        if self.input == IN_I16_IQ:
+        if self.input in (IN_I16_IQ, IN_I16_QI):
             a = np.ascontiguousarray(x, dtype=np.int16).reshape(-1)
+            return a, a.size // 2
+        if self.input == IN_I8_IQ:
+            a = np.ascontiguousarray(x, dtype=np.int8).reshape(-1)
             return a, a.size // 2
         if self.input == IN_CF32:
             a = np.ascontiguousarray(x, dtype=np.complex64).reshape(-1)

@@ -24,6 +24,18 @@ int ensure_device();          // SDR_OK or SDR_ENODEV / SDR_EHIP
 
 // 2^-11: the Q11 scale of BLADERF_FORMAT_SC16_Q11 samples (bladerf_sdr.h:274)
 constexpr float kQ11 = 1.0f / 2048.0f;
+// 2^-7: full scale of the HackRF's int8 samples
+constexpr float kQ7 = 1.0f / 128.0f;
+
+// bytes of one input sample of kind `input` (sdr_input)
+inline size_t in_elem_bytes(int input)
+{
+    switch (input) {
+    case SDR_IN_CF32: return 8;
+    case SDR_IN_I8_IQ: return 2;
+    default: return 4;
+    }
+}
 
 }  // namespace sdr
 

@@ -19,7 +19,7 @@ extern "C" int sdr_fir_plan_shape(const sdr_fir_plan *p, int *input, int *mode, 
 
 namespace {
 constexpr int kSlots = 2;
-size_t in_bytes(int input) { return input == SDR_IN_CF32 ? 8 : 4; }
+size_t in_bytes(int input) { return sdr::in_elem_bytes(input); }
 size_t out_bytes(int mode) { return mode == SDR_MODE_IQ ? 8 : 4; }
 }
 

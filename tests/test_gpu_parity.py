@@ -382,3 +382,60 @@ def test_fft_power_db(sdr, oracle, golden, nfft):
 def test_fft_exact_zero_gives_minus_inf(sdr):
     got = sdr.FftPlan(256, 128).execute_host(np.zeros(2 * 512, np.int16))
     assert got.shape == (3, 256) and np.all(np.isneginf(got))
+
+
+@pytest.mark.gpu
+def test_wire_formats(sdr, oracle):
+    """Q-first int16 (B205 recordings) on every kernel, int8 pairs (HackRF) on the
+    streaming kernel, against the oracle chain run on the unpacked samples."""
+    rng = np.random.default_rng(77)
+    n = 200_003
+    T, D = 64, 10
+    h = oracle.create_fir_filter(T, 0.08, "hann")
+    iq = oracle.synth_fm_i16(n, fs=1.0e6, ftone=2500.0, dev=30000.0, amp=1800.0)
+    iq = (iq + rng.integers(-30, 31, iq.size)).astype(np.int16)
+    qi = iq.reshape(-1, 2)[:, ::-1].reshape(-1).copy()
+    y = oracle.chain_i16(iq, D, h, oracle.MODE_IQ)
+    fm = oracle.chain_i16(iq, D, h, oracle.MODE_FM)
+    env = oracle.chain_i16(iq, D, h, oracle.MODE_ENV)
+    assert np.array_equal(oracle.unpack_scale_i16_qi(qi), oracle.unpack_scale_i16(iq))
+    for pipe in (1, 2, 3):
+        tag = f"QI pipe={pipe}"
+        check_fm(sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I16_QI, pipeline=pipe).execute_host(qi),
+                 fm, y, 1 / TWO_PI, tag)
+        check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_I16_QI, pipeline=pipe).execute_host(qi), env, tag)
+        check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=sdr.IN_I16_QI, pipeline=pipe).execute_host(qi), y, tag)
+    # Q-first with the mixer (streaming kernel): the swap must happen before the rotation
+    fr = 0.0123
+    xs = oracle.frequency_shift(oracle.unpack_scale_i16(iq), fr)
+    ys = oracle.fir_decimate(xs, D, h)
+    check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=sdr.IN_I16_QI, mix_fr=fr).execute_host(qi), ys, "QI mixer")
+
+    # int8 pairs
+    b = rng.integers(-128, 128, 2 * n).astype(np.int8)
+    ph = 2 * np.pi * np.cumsum(0.01 + 0.004 * np.sin(2 * np.pi * 1e-3 * np.arange(n)))
+    b[0::2] = np.clip(np.rint(100 * np.cos(ph)) + rng.integers(-3, 4, n), -128, 127).astype(np.int8)
+    b[1::2] = np.clip(np.rint(100 * np.sin(ph)) + rng.integers(-3, 4, n), -128, 127).astype(np.int8)
+    x8 = oracle.unpack_scale_i8(b)
+    y8 = oracle.fir_decimate(x8, D, h)
+    fm8 = oracle.polar_discriminator(y8, 1 / TWO_PI)
+    for R, NT in ((0, 0), (1, 64), (4, 128)):
+        tag = f"int8 R={R} NT={NT}"
+        p = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I8_IQ, outputs_per_lane=R, threads=NT)
+        assert p.info()["kernel"] == "stream"
+        check_fm(p.execute_host(b), fm8, y8, 1 / TWO_PI, tag)
+        check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_I8_IQ, outputs_per_lane=R,
+                                 threads=NT).execute_host(b), np.abs(y8), tag)
+        check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=sdr.IN_I8_IQ, outputs_per_lane=R,
+                                 threads=NT).execute_host(b), y8, tag)
+    # odd byte address (sample-aligned only): the checked path
+    d_in = sdr.DevBuf(2 * n + 16)
+    import ctypes
+    sdr.capi.check(sdr.capi.lib().sdr_dev_upload(d_in.at(2), b.ctypes.data_as(ctypes.c_void_p),
+                                                 ctypes.c_size_t(2 * n)))
+    p = sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=sdr.IN_I8_IQ)
+    cnt = p.out_count(n)
+    d_out = sdr.DevBuf(cnt * 8)
+    p.execute_dev(d_in.at(2), n, d_out, cnt)
+    sdr.sync()
+    check_linear(d_out.to_numpy(np.complex64, cnt), y8, "int8 misaligned")

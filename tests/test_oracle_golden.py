@@ -163,3 +163,18 @@ def test_windows_and_designer_unpinned(oracle):
         assert abs(h.sum() - 1.0) < 0.01                         # ~unity DC gain
         H = np.abs(np.fft.fft(h, 8192))
         assert H[int(0.02 * 8192)] > 0.95 and H[int(0.2 * 8192)] < 1e-2
+
+
+def test_wire_format_unpackers(oracle):
+    """SURVEY 8(f2) layouts: Q-first int16 and int8 pairs.  No reference function exists for them
+    in the tree (the readers are in the un-vendored Common repository) -- parity unpinned; the
+    known answers below pin the layout and the exact power-of-two scales."""
+    qi = np.array([-2048, 2047, 1, -1, 32767, -32768], np.int16)        # (Q, I) pairs
+    x = oracle.unpack_scale_i16_qi(qi)
+    assert np.array_equal(x, np.array([2047 - 2048j, -1 + 1j, -32768 + 32767j]) / 2048.0)
+    # the same samples, I first, through the reference-pinned unpacker
+    iq = qi.reshape(-1, 2)[:, ::-1].reshape(-1)
+    assert np.array_equal(x, oracle.unpack_scale_i16(iq))
+    b = np.array([-128, 127, 0, -1, 64, 5], np.int8)
+    y = oracle.unpack_scale_i8(b)
+    assert np.array_equal(y, np.array([-128 + 127j, 0 - 1j, 64 + 5j]) / 128.0)

@@ -1,0 +1,119 @@
+// Micro-benchmark: what a read-dominated stream with the FIR chain's byte ratio (4 B in per
+// sample, 0.4 B out) reaches on this GPU, without any of the FIR's work: every lane reads 16-byte
+// pieces, xors them together and one lane in ten stores a float.  Variants: plain vector loads
+// (grid-stride and one-tile-per-workgroup) and LDS-DMA tiles as the FIR kernel stages them.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+__global__ void __launch_bounds__(256) read_gridstride(const uint4 *in, float *out, size_t n16)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    unsigned acc = 0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+        if ((threadIdx.x % 10) < 4) out[(i * 4) / 10] = __uint_as_float(acc);
+    }
+}
+
+// one 20 KB tile per workgroup (5 x 16 B per lane), like the FIR kernel's tiles
+__global__ void __launch_bounds__(256) read_tiles(const uint4 *in, float *out, size_t n16)
+{
+    const size_t base = (size_t)blockIdx.x * 1280;
+    unsigned acc = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint4 a = in[base + k * 256 + threadIdx.x];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w;
+    }
+    // 512 floats out per tile
+    ((float2 *)out)[(size_t)blockIdx.x * 256 + threadIdx.x] = make_float2(__uint_as_float(acc), 1.f);
+}
+
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+
+__global__ void __launch_bounds__(256) read_tiles_dma(const uint4 *in, float *out, size_t n16)
+{
+    __shared__ uint4 tile[1280 + 256];
+    const size_t base = (size_t)blockIdx.x * 1280;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(tile + k * 256 + (tid & ~63));
+        dma16(in + base + k * 256 + tid, __builtin_amdgcn_readfirstlane(lds));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint4 a = tile[(tid * 5) % 1280];
+    ((float2 *)out)[(size_t)blockIdx.x * 256 + tid] = make_float2(__uint_as_float(a.x ^ a.y ^ a.z ^ a.w), 1.f);
+}
+
+// variants of the tile kernel: K pieces per lane, optional non-temporal loads, optional XCD-contiguous
+// tile order (workgroup b runs on XCD b % 8; give every XCD one contiguous eighth of the stream)
+template <int K, bool NT, bool XCD>
+__global__ void __launch_bounds__(256) read_tiles_v(const uint4 *in, float *out, size_t n16)
+{
+    size_t tile = blockIdx.x;
+    if (XCD) tile = (size_t)(blockIdx.x & 7) * (gridDim.x / 8) + (blockIdx.x >> 3);
+    const size_t base = tile * (256 * K);
+    unsigned acc = 0;
+    uint4 a[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint4 *p = in + base + k * 256 + threadIdx.x;
+        if (NT) {
+            a[k].x = __builtin_nontemporal_load(&p->x); a[k].y = __builtin_nontemporal_load(&p->y);
+            a[k].z = __builtin_nontemporal_load(&p->z); a[k].w = __builtin_nontemporal_load(&p->w);
+        } else a[k] = *p;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w;
+    if (K >= 5) {
+#pragma unroll
+        for (int j = 0; j < K / 5; ++j)
+            ((float2 *)out)[(tile * (K / 5) + j) * 256 + threadIdx.x] = make_float2(__uint_as_float(acc), 1.f);
+    }
+}
+
+int main()
+{
+    const size_t n = (size_t)1 << 30;          // samples, 4 B each
+    const size_t n16 = n / 4;
+    uint4 *in; float *out;
+    hipMalloc(&in, n * 4 + 65536);
+    hipMalloc(&out, n / 10 * 4 + (1 << 22));
+    hipMemset(in, 1, n * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const double bytes = 4.4 * (double)n;
+    for (int variant = 0; variant < 9; ++variant) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(e0);
+            for (int it = 0; it < 20; ++it) {
+                if (variant == 0) read_gridstride<<<256 * 8, 256>>>(in, out, n16);
+                if (variant == 1) read_gridstride<<<256 * 32, 256>>>(in, out, n16);
+                if (variant == 2) read_tiles<<<(unsigned)(n16 / 1280), 256>>>(in, out, n16);
+                if (variant == 3) read_tiles_dma<<<(unsigned)(n16 / 1280), 256>>>(in, out, n16);
+                if (variant == 4) read_tiles_v<10, false, false><<<(unsigned)(n16 / 2560), 256>>>(in, out, n16);
+                if (variant == 5) read_tiles_v<5, true, false><<<(unsigned)(n16 / 1280), 256>>>(in, out, n16);
+                if (variant == 6) read_tiles_v<5, false, true><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 7) read_tiles_v<20, false, false><<<(unsigned)(n16 / 5120), 256>>>(in, out, n16);
+                if (variant == 8) read_tiles_v<10, true, true><<<(unsigned)(n16 / 2560) & ~7u, 256>>>(in, out, n16);
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+            if (rep && ms < best) best = ms;
+        }
+        const char *nm[9] = {"grid-stride 8 wg/CU", "grid-stride 32 wg/CU", "20 KB tile per wg, vector loads", "20 KB tile per wg, LDS-DMA", "40 KB tile", "20 KB tile, nontemporal", "20 KB tile, XCD-contiguous", "80 KB tile", "40 KB nontemporal XCD-contiguous"};
+        printf("%-34s %.4f ms  %.0f GB/s (4.4 B/sample)\n", nm[variant], best, bytes / best / 1e6);
+    }
+    return 0;
+}

@@ -216,6 +216,16 @@ int sdr_fir_stream_create(sdr_fir_plan *plan, size_t max_block_samples, sdr_fir_
 int sdr_fir_stream_destroy(sdr_fir_stream *stream);
 int sdr_fir_stream_push(sdr_fir_stream *stream, const void *block_host, size_t n_samples);
 int sdr_fir_stream_pop(sdr_fir_stream *stream, void *out_host, size_t capacity, size_t *n_out);
+/* File replay source.  Replaces temp_get_data (bladerf/apt_demod/src/bladerf_apt_demod.cpp:92-148):
+ * the raw sample file at `path` (samples of the plan's input kind, e.g. a .sc16 recording) is cut
+ * to a multiple of two blocks (:113-117) and pushed block by block, `passes` times over (the
+ * reference cycles until stopped, :139-145).  `sink` is called once per block, in order, with that
+ * block's outputs (elements of the plan's output type); a non-zero return stops the replay
+ * (SDR_ERANGE).  The stream is left empty.  *samples_replayed (optional) = samples pushed. */
+typedef int (*sdr_block_sink)(void *user, const void *outputs, size_t n_outputs);
+int sdr_fir_stream_replay_file(sdr_fir_stream *stream, const char *path, size_t block_samples,
+                               int passes, sdr_block_sink sink, void *user,
+                               uint64_t *samples_replayed);
 /* input kind, mode, decimation and tap count of a plan */
 int sdr_fir_plan_shape(const sdr_fir_plan *plan, int *input, int *mode, int *decim, int *n_taps);
 

@@ -350,6 +350,24 @@ class FirStream:
                                        C.byref(n)))
         return out[: n.value].copy()
 
+    def replay_file(self, path, block_samples, passes=1):
+        """sdr_fir_stream_replay_file: returns (outputs of all blocks concatenated, samples pushed)"""
+        chunks = []
+        dt = self.plan.out_dtype
+        size = np.dtype(dt).itemsize
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+        def sink(_user, ptr, n):
+            if n:
+                chunks.append(np.frombuffer(C.string_at(ptr, n * size), dtype=dt).copy())
+            return 0
+
+        done = C.c_uint64()
+        check(lib().sdr_fir_stream_replay_file(self.h, str(path).encode(), C.c_size_t(block_samples),
+                                               C.c_int(passes), sink, None, C.byref(done)))
+        out = np.concatenate(chunks) if chunks else np.empty(0, dt)
+        return out, done.value
+
     def destroy(self):
         if self.h and self.h.value:
             lib().sdr_fir_stream_destroy(self.h)

@@ -10,7 +10,9 @@
 // outputs that became computable, and pop() hands them back in order.  Two slots alternate so
 // that the producer can fill slot k+1 while slot k is still in flight.
 
+#include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "sdr_internal.h"
 
@@ -138,4 +140,62 @@ extern "C" int sdr_fir_stream_pop(sdr_fir_stream *s, void *out, size_t capacity,
     s->busy[k] = false;
     s->tail = (k + 1) % kSlots;
     return SDR_OK;
+}
+
+// File replay: the reference's stand-in for a live capture,
+//   temp_get_data                    bladerf/apt_demod/src/bladerf_apt_demod.cpp:92-148
+// reads a raw sample file (.sc16: interleaved int16 I,Q as rx_record writes it,
+// bladerf_rec_main_v1.cpp:169), drops the tail so that the length is a multiple of two capture
+// blocks (:113-117), and hands the blocks to the consumer one after the other, starting over at
+// the end of the file (:139-145).  Here: the same blocks go through push/pop; `passes` bounds the
+// cycling (the reference cycles until it is stopped); the sink sees every block's outputs in
+// order.  Filter history persists across blocks and across the wrap-around, as everywhere in
+// this hand-off (the reference filters each block from zero state).
+extern "C" int sdr_fir_stream_replay_file(sdr_fir_stream *s, const char *path, size_t block_samples,
+                                          int passes, sdr_block_sink sink, void *user,
+                                          uint64_t *samples_replayed)
+{
+    if (!s || !path || !sink || block_samples == 0 || passes <= 0) { sdr::set_error("bad argument"); return SDR_EINVAL; }
+    if (block_samples > s->max_block) { sdr::set_error("block of %zu samples exceeds max_block %zu", block_samples, s->max_block); return SDR_EINVAL; }
+    if (samples_replayed) *samples_replayed = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) { sdr::set_error("cannot open %s", path); return SDR_EINVAL; }
+    const size_t ib = in_bytes(s->input), ob = out_bytes(s->mode);
+    if (fseek(f, 0, SEEK_END) != 0) { fclose(f); sdr::set_error("cannot seek %s", path); return SDR_EINVAL; }
+    const long long fbytes = ftell(f);
+    unsigned long long n_file = fbytes > 0 ? (unsigned long long)fbytes / ib : 0;
+    n_file -= n_file % (2ULL * block_samples);                  // :113-117
+    if (n_file == 0) { fclose(f); sdr::set_error("%s holds less than two blocks of %zu samples", path, block_samples); return SDR_EINVAL; }
+    std::vector<unsigned char> blk(block_samples * ib);
+    const size_t cap = (s->halo + s->max_block) / (size_t)s->D + 2;
+    std::vector<unsigned char> outbuf(cap * ob);
+    int rc = SDR_OK;
+    unsigned long long done = 0;
+    int in_flight = 0;
+    auto drain_one = [&]() -> int {
+        size_t n_out = 0;
+        int r = sdr_fir_stream_pop(s, outbuf.data(), cap, &n_out);
+        if (r != SDR_OK) return r;
+        --in_flight;
+        return sink(user, outbuf.data(), n_out) == 0 ? SDR_OK : SDR_ERANGE;
+    };
+    for (int pass = 0; pass < passes && rc == SDR_OK; ++pass) {
+        if (fseek(f, 0, SEEK_SET) != 0) { sdr::set_error("cannot rewind %s", path); rc = SDR_EINVAL; break; }
+        for (unsigned long long at = 0; at < n_file && rc == SDR_OK; at += block_samples) {
+            if (fread(blk.data(), ib, block_samples, f) != block_samples) { sdr::set_error("short read from %s", path); rc = SDR_EINVAL; break; }
+            if (in_flight == kSlots) rc = drain_one();          // keep one block in flight behind the read
+            if (rc != SDR_OK) break;
+            rc = sdr_fir_stream_push(s, blk.data(), block_samples);
+            if (rc == SDR_OK) { ++in_flight; done += block_samples; }
+        }
+    }
+    while (in_flight > 0) {                                     // always leave the stream empty
+        const int r = drain_one();
+        if (rc == SDR_OK) rc = r;
+        if (r != SDR_OK && r != SDR_ERANGE) break;
+    }
+    fclose(f);
+    if (rc == SDR_ERANGE) sdr::set_error("sink stopped the replay");
+    if (samples_replayed) *samples_replayed = done;
+    return rc;
 }

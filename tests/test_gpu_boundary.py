@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+TWO_PI = 2.0 * np.pi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXAMPLE = os.path.join(ROOT, "examples", "bin", "apt_chain_example")
@@ -86,3 +87,43 @@ def test_stream_blocks_equal_one_shot(sdr, oracle, mode):
     # the reference's per-block restart differs from this at every block start (the transient)
     with pytest.raises(sdr.SdrError):
         stream.push(iq[: 2 * 10]); stream.push(iq[: 2 * 10]); stream.push(iq[: 2 * 10])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sc16", "qi16", "i8"])
+def test_file_replay(sdr, oracle, tmp_path, kind):
+    """f2: replaying a recording (temp_get_data, bladerf_apt_demod.cpp:92-148) == the one-shot chain
+    on the file cut to a multiple of two blocks (:113-117); a second pass continues the same
+    stream (history kept across the wrap-around)."""
+    rng = np.random.default_rng(5)
+    blk = 40_000
+    n = 5 * blk + 1234                      # -> 4 blocks kept
+    D, T = 10, 64
+    h = oracle.create_fir_filter(T, 0.09, "hann")
+    iq = oracle.synth_fm_i16(n, fs=1.0e6, ftone=1200.0, dev=25000.0, amp=1500.0)
+    iq = (iq + rng.integers(-20, 21, iq.size)).astype(np.int16)
+    if kind == "sc16":
+        data, inp, x = iq, sdr.IN_I16_IQ, oracle.unpack_scale_i16(iq)
+    elif kind == "qi16":
+        data, inp, x = iq.reshape(-1, 2)[:, ::-1].reshape(-1).copy(), sdr.IN_I16_QI, oracle.unpack_scale_i16(iq)
+    else:
+        data = (iq >> 4).astype(np.int8)
+        inp, x = sdr.IN_I8_IQ, oracle.unpack_scale_i8((iq >> 4).astype(np.int8))
+    path = tmp_path / f"capture.{kind}"
+    data.tofile(path)
+    kept = 4 * blk
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=inp)
+    stream = sdr.FirStream(plan, blk)
+    got, pushed = stream.replay_file(path, blk, passes=2)
+    assert pushed == 2 * kept
+    xx = np.concatenate([x[:kept], x[:kept]])
+    y = oracle.fir_decimate(xx, D, h)
+    want = oracle.polar_discriminator(y, 1 / TWO_PI)
+    from test_gpu_parity import check_fm
+    check_fm(got, want, y, 1 / TWO_PI, kind)
+    # errors: missing file, file shorter than two blocks
+    with pytest.raises(sdr.SdrError):
+        stream.replay_file(tmp_path / "nope.sc16", blk)
+    data[: 2 * blk].tofile(tmp_path / "short.bin")
+    with pytest.raises(sdr.SdrError):
+        stream.replay_file(tmp_path / "short.bin", blk)

@@ -47,7 +47,10 @@ enum sdr_status {
 enum sdr_mode {
     SDR_MODE_IQ = 0,    /* complex y[m] (float2)           -- polyphase_decimate alone        */
     SDR_MODE_FM = 1,    /* scale*arg(y[m+1] conj(y[m]))    -- + polar_discriminator           */
-    SDR_MODE_ENV = 2    /* |y[m]|                          -- + std::abs envelope             */
+    SDR_MODE_ENV = 2,   /* |y[m]|                          -- + std::abs envelope             */
+    SDR_MODE_REAL = 3   /* Re y[m] (float): real-input filters, e.g. the FM audio post filters
+                           af::fir(af_lpf_de, x5), af::fir(af_lpf_a, x6) + x6(seq_audio)
+                           (bladerf/rx_fm_demod/src/bladerf_fm_demod.cpp:301-307)           */
 };
 
 /* sample type of the input stream */
@@ -179,6 +182,13 @@ int sdr_fft_execute_i16_dev(sdr_fft_plan *plan, const int16_t *d_iq, size_t n_in
 /* ---- a6 (waterfall row): |x|/2048 straight from int16 --------------------------------------
  * Replaces the std::transform at bladerf_waterfall_main.cpp:272. */
 int sdr_magnitude_i16_dev(const int16_t *d_iq, size_t n, float *d_mag, void *stream);
+
+/* ---- f1: FM audio PCM stage --------------------------------------------------------------------
+ * Replaces bladerf_fm_demod.cpp:310-313:  x7 = x7 * (1.0 / max(abs(x7)));  x7 = ((x7+1)*30).as(u8).
+ * d_x: n floats (the decimated audio, e.g. a SDR_MODE_REAL plan's output); d_max: one float of
+ * device scratch (receives max|x|); d_pcm: n bytes.  An all-zero block gives 30 everywhere (the
+ * reference divides by zero there).  The float -> u8 conversion truncates like as(u8). */
+int sdr_audio_u8_dev(const float *d_x, size_t n, float *d_max, uint8_t *d_pcm, void *stream);
 
 /* ---- a2 alone: int16 -> complex float, x 1/2048 ---------------------------------------------
  * Replaces the scale loop of bladerf_sdr.h:288-291,334-337 for callers that want the float

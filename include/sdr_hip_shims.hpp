@@ -89,6 +89,35 @@ inline std::vector<float> shift_decimate_envelope(const std::vector<float>& x, d
     return plan.run<float, float>(x.data(), x.size());
 }
 
+// bladerf_fm_demod.cpp:301-313: de-emphasis FIR, audio low-pass FIR, pick every dec_audio-th sample,
+// normalise to +-1 and convert to unsigned 8-bit PCM.  The two full-rate filters are folded into
+// one (their convolution), so only the kept samples are computed -- one real-input FIR/decimate
+// launch plus the PCM stage.
+inline std::vector<uint8_t> fm_audio_u8(const std::vector<float>& x5, const std::vector<float>& lpf_de,
+                                        const std::vector<float>& lpf_a, int dec_audio)
+{
+    std::vector<double> hc(lpf_de.size() + lpf_a.size() - 1, 0.0);
+    for (size_t i = 0; i < lpf_de.size(); ++i)
+        for (size_t j = 0; j < lpf_a.size(); ++j) hc[i + j] += (double)lpf_de[i] * (double)lpf_a[j];
+    FirPlan plan(hc, dec_audio, SDR_MODE_REAL, SDR_IN_F32_REAL);
+    const size_t m = plan.out_count(x5.size());
+    std::vector<uint8_t> pcm(m);
+    if (m == 0) return pcm;
+    void *d_in = nullptr, *d_a = nullptr, *d_pcm = nullptr;
+    int rc = sdr_dev_alloc(&d_in, x5.size() * sizeof(float));
+    if (rc == SDR_OK) rc = sdr_dev_alloc(&d_a, (m + 1) * sizeof(float));       // audio + the max scratch
+    if (rc == SDR_OK) rc = sdr_dev_alloc(&d_pcm, m);
+    if (rc == SDR_OK) rc = sdr_dev_upload(d_in, x5.data(), x5.size() * sizeof(float));
+    size_t n_out = 0;
+    if (rc == SDR_OK) rc = sdr_fir_execute_dev(plan.get(), d_in, x5.size(), d_a, m, &n_out, nullptr);
+    if (rc == SDR_OK) rc = sdr_audio_u8_dev((const float*)d_a, m, (float*)d_a + m, (uint8_t*)d_pcm, nullptr);
+    if (rc == SDR_OK) rc = sdr_dev_sync();
+    if (rc == SDR_OK) rc = sdr_dev_download(pcm.data(), d_pcm, m);
+    sdr_dev_free(d_in); sdr_dev_free(d_a); sdr_dev_free(d_pcm);
+    check(rc);
+    return pcm;
+}
+
 }  // namespace sdrhip
 
 // =============================================================================================

@@ -80,6 +80,7 @@ def lib():
         L.orc_fft_power_db_i16.restype = C.c_size_t
         L.orc_chain_i16.restype = C.c_size_t
         L.orc_apt_chain_i16.restype = C.c_size_t
+        L.orc_fm_audio_chain.restype = C.c_size_t
         _oracle = L
     return _oracle
 
@@ -384,3 +385,17 @@ def ref_time_chain_i16(iq, D, h, mode, scale, reps):
     return ref().ref_time_chain_i16(_s(iq), C.c_size_t(iq.size // 2), C.c_int(D), _d(h),
                                     C.c_int(h.size), C.c_int(mode), C.c_double(scale),
                                     C.c_int(reps), C.byref(sink))
+
+
+def fm_audio_chain(x5, h_de, h_a, D):
+    """bladerf_fm_demod.cpp:301-313 -> (normalised audio float64, pcm uint8)"""
+    x = _f64(x5)
+    h_de = _f64(h_de)
+    h_a = _f64(h_a)
+    m = x.size // D
+    audio = np.zeros(max(m, 1), np.float64)
+    pcm = np.zeros(max(m, 1), np.uint8)
+    k = lib().orc_fm_audio_chain(_d(x), C.c_size_t(x.size), _d(h_de), C.c_int(h_de.size), _d(h_a),
+                                 C.c_int(h_a.size), C.c_int(D), _d(audio),
+                                 pcm.ctypes.data_as(C.c_void_p))
+    return audio[:k], pcm[:k]

@@ -480,3 +480,43 @@ void orc_synth_fm_i16(int16_t *iq, size_t n, uint64_t n0, double fs, double fton
         iq[2 * j + 1] = (int16_t)lrint(amp * sin(ph));
     }
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * f1: FM audio post-chain -- bladerf/rx_fm_demod/src/bladerf_fm_demod.cpp:301-313
+ *   x6 = af::fir(af_lpf_de, x5);  x6 = af::fir(af_lpf_a, x6);  x7 = x6(seq_audio);
+ *   x7 = x7 * (1.0 / max(abs(x7)));  x7 = ((x7 + 1) * 30).as(u8);
+ * af::fir is the causal, length-preserving FIR from zero state.  ArrayFire is not in
+ * the tree: PARITY UNPINNED beyond these documented semantics.  Divergences restated from the
+ * build: kept indices are m*D for m < floor(n/D) (the reference's af::seq end is inclusive and can
+ * index one past the data); an all-zero block gives 30 (the reference divides by zero).
+ * x5: n floats as doubles; audio (optional): floor(n/D) normalised values before quantisation;
+ * pcm: floor(n/D) bytes.  Returns floor(n/D). */
+size_t orc_fm_audio_chain(const double *x5, size_t n, const double *h_de, int T_de,
+                          const double *h_a, int T_a, int D, double *audio, uint8_t *pcm)
+{
+    if (D <= 0 || T_de <= 0 || T_a <= 0) return 0;
+    double *a = (double *)calloc(n ? n : 1, sizeof(double));
+    double *b = (double *)calloc(n ? n : 1, sizeof(double));
+    for (size_t i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int k = 0; k < T_de && (size_t)k <= i; ++k) acc += h_de[k] * x5[i - k];
+        a[i] = acc;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int k = 0; k < T_a && (size_t)k <= i; ++k) acc += h_a[k] * a[i - k];
+        b[i] = acc;
+    }
+    const size_t m = n / (size_t)D;
+    double mx = 0.0;
+    for (size_t j = 0; j < m; ++j) { const double v = fabs(b[j * D]); if (v > mx) mx = v; }
+    const double r = mx > 0.0 ? 1.0 / mx : 0.0;
+    for (size_t j = 0; j < m; ++j) {
+        const double v = b[j * D] * r;
+        if (audio) audio[j] = v;
+        pcm[j] = (uint8_t)(int)((v + 1.0) * 30.0);
+    }
+    free(a); free(b);
+    return m;
+}

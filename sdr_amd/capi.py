@@ -16,7 +16,7 @@ SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "strea
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 OK, EINVAL, ENOMEM, EHIP, EALIGN, ECAPACITY, ENODEV, ERANGE = range(8)
-MODE_IQ, MODE_FM, MODE_ENV = 0, 1, 2
+MODE_IQ, MODE_FM, MODE_ENV, MODE_REAL = 0, 1, 2, 3
 IN_I16_IQ, IN_CF32, IN_F32_REAL, IN_I16_QI, IN_I8_IQ = 0, 1, 2, 3, 4
 WINDOWS = {"rectangular": 0, "hann": 1, "hamming": 2, "blackman": 3, "nuttall": 4,
            "blackman_harris": 5}
@@ -314,6 +314,10 @@ def unpack_i16_dev(d_iq, n, d_out, stream=None):
 def magnitude_i16_dev(d_iq, n, d_out, stream=None):
     check(lib().sdr_magnitude_i16_dev(_vp(d_iq), C.c_size_t(n), _vp(d_out),
                                       C.c_void_p(stream or 0)))
+
+
+def audio_u8_dev(d_x, n, d_max, d_pcm, stream=None):
+    check(lib().sdr_audio_u8_dev(_vp(d_x), C.c_size_t(n), _vp(d_max), _vp(d_pcm), C.c_void_p(stream or 0)))
 
 
 def frequency_shift_dev(d_in, is_complex, n, n0, fr, d_out, stream=None):

@@ -171,6 +171,9 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
     if (g.mode == SDR_MODE_FM) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = discriminate(r + 1 < R ? y[r + 1] : ynext, y[r], g.scale);
+    } else if (g.mode == SDR_MODE_REAL) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = y[r].x;
     } else {
 #pragma unroll
         // std::abs(complex): |y| <= 16*sum|h| here, so the plain form cannot overflow; a result
@@ -927,7 +930,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->n_taps <= 0 || !d->taps) { sdr::set_error("n_taps must be positive"); return SDR_EINVAL; }
     if (d->n_taps > 16384) { sdr::set_error("n_taps > 16384 unsupported"); return SDR_EINVAL; }
     if (d->input < SDR_IN_I16_IQ || d->input > SDR_IN_I8_IQ) { sdr::set_error("bad input kind"); return SDR_EINVAL; }
-    if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_ENV) { sdr::set_error("bad mode"); return SDR_EINVAL; }
+    if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_REAL) { sdr::set_error("bad mode"); return SDR_EINVAL; }
     if (d->pipeline < 0 || d->pipeline > 3) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;

@@ -255,6 +255,49 @@ unsigned stream_grid(size_t work_items)
 
 }  // namespace
 
+// max|x| of a float vector: wave reduction, then one global atomic per wave on the bit pattern
+// (non-negative floats order like unsigned integers)
+__global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x, size_t n,
+                                                     unsigned *__restrict__ mx)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(mx, __float_as_uint(m));
+}
+
+// bladerf_fm_demod.cpp:310-313: x * (1/max) -> (x + 1) * 30 -> u8 (truncation)
+__global__ void __launch_bounds__(256) audio_u8_kernel(const float *__restrict__ x, size_t n,
+                                                       const float *__restrict__ mx,
+                                                       uint8_t *__restrict__ out)
+{
+    const float m = *mx;
+    const float r = m > 0.f ? (float)(1.0 / (double)m) : 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = (x[i] * r + 1.0f) * 30.0f;
+        out[i] = (uint8_t)(int)v;
+    }
+}
+
+extern "C" int sdr_audio_u8_dev(const float *d_x, size_t n, float *d_max, uint8_t *d_pcm, void *stream)
+{
+    if (n == 0) return SDR_OK;
+    if (!d_x || !d_max || !d_pcm) { sdr::set_error("null argument"); return SDR_EINVAL; }
+    if (((uintptr_t)d_x) & 3 || ((uintptr_t)d_max) & 3) return SDR_EALIGN;
+    int rc = sdr::ensure_device();
+    if (rc != SDR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    SDR_HIP(hipMemsetAsync(d_max, 0, sizeof(float), st));
+    absmax_kernel<<<stream_grid(n), 256, 0, st>>>(d_x, n, (unsigned *)d_max);
+    SDR_HIP(hipGetLastError());
+    audio_u8_kernel<<<stream_grid(n), 256, 0, st>>>(d_x, n, d_max, d_pcm);
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
 extern "C" int sdr_unpack_i16_dev(const int16_t *d_iq, size_t n, float *d_out, void *stream)
 {
     if (n == 0) return SDR_OK;

@@ -11,7 +11,7 @@ in the CPU tests).  No reference counterpart: the reference is single-process
 """
 from dataclasses import dataclass
 
-MODE_IQ, MODE_FM, MODE_ENV = 0, 1, 2
+MODE_IQ, MODE_FM, MODE_ENV, MODE_REAL = 0, 1, 2, 3
 
 
 def out_count(n_samples, decim, mode):

@@ -439,3 +439,57 @@ def test_wire_formats(sdr, oracle):
     p.execute_dev(d_in.at(2), n, d_out, cnt)
     sdr.sync()
     check_linear(d_out.to_numpy(np.complex64, cnt), y8, "int8 misaligned")
+
+
+@pytest.mark.gpu
+def test_fm_audio_post_chain(sdr, oracle):
+    """f1: bladerf_fm_demod.cpp:301-313 -- de-emphasis + audio low-pass + pick + normalise + u8.
+    ArrayFire is not in the tree (parity unpinned); the oracle restates the documented semantics
+    in f64.  The GPU folds both filters into one real-input FIR/decimate (SDR_MODE_REAL)."""
+    rng = np.random.default_rng(3)
+    n = 150_001
+    t = np.arange(n)
+    x5 = (0.3 * np.sin(2 * np.pi * 0.003 * t) + 0.1 * np.sin(2 * np.pi * 0.041 * t)
+          + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    h_de = oracle.create_fir_filter(64, 1.0 / (200e3 * 75e-6), "rectangular").astype(np.float32)
+    h_a = oracle.create_fir_filter(101, (10e3 / 2.0) / 200e3, "hann").astype(np.float32)
+    D = 20
+    audio, pcm = oracle.fm_audio_chain(x5, h_de, h_a, D)
+    hc = np.convolve(h_de.astype(np.float64), h_a.astype(np.float64))
+    plan = sdr.FirPlan(hc, D, mode=sdr.MODE_REAL, input=sdr.IN_F32_REAL)
+    got = plan.execute_host(x5)
+    assert got.dtype == np.float32 and got.size == audio.size == n // D
+    mx = float(np.abs(got).max())
+    check_linear(got / mx, audio, "audio")
+    m = got.size
+    d_x = sdr.DevBuf.from_numpy(got)
+    d_max = sdr.DevBuf(4)
+    d_pcm = sdr.DevBuf(m)
+    sdr.capi.audio_u8_dev(d_x, m, d_max, d_pcm)
+    sdr.sync()
+    assert d_max.to_numpy(np.float32, 1)[0] == np.float32(mx)
+    out = d_pcm.to_numpy(np.uint8, m)
+    # bit-exact against the same float32 arithmetic on the host ...
+    r = np.float32(1.0 / np.float64(np.float32(mx)))
+    ref32 = ((got * r + np.float32(1.0)) * np.float32(30.0)).astype(np.int32).astype(np.uint8)
+    assert np.array_equal(out, ref32)
+    # ... and within one code of the f64 oracle (values that sit on a truncation boundary)
+    d = np.abs(out.astype(np.int32) - pcm.astype(np.int32))
+    assert d.max() <= 1 and np.count_nonzero(d) <= max(4, m // 1000), (d.max(), np.count_nonzero(d))
+    assert out.min() >= 0 and out.max() <= 60
+    # all-zero block: 30 everywhere, max 0
+    z = sdr.DevBuf.from_numpy(np.zeros(1000, np.float32))
+    sdr.capi.audio_u8_dev(z, 1000, d_max, d_pcm)
+    sdr.sync()
+    assert np.all(d_pcm.to_numpy(np.uint8, 1000) == 30)
+    # other real-output shapes through every geometry that fits
+    x = rng.standard_normal(60_007).astype(np.float32)
+    for T, Dd in ((7, 1), (64, 4), (165, 20), (511, 15)):
+        h = oracle.create_fir_filter(T, min(0.8 / Dd, 0.9), "hann")
+        y = oracle.fir_decimate(x.astype(np.complex128), Dd, h).real
+        for R in (0, 1, 2, 4):
+            try:
+                p = sdr.FirPlan(h, Dd, mode=sdr.MODE_REAL, input=sdr.IN_F32_REAL, outputs_per_lane=R)
+            except sdr.SdrError:
+                continue
+            check_linear(p.execute_host(x), y, f"real T={T} D={Dd} R={R}")

@@ -75,6 +75,15 @@ int main(int argc, char** argv)
         std::vector<double> h7 = {0.1, -0.2, 0.3, 0.4, 0.3, -0.2, 0.1};
         std::vector<double> filt = filter_vec(x6, h7);
 
+        // the FM receiver's audio stage (bladerf_fm_demod.cpp:301-313) on the discriminator output:
+        // 64-tap rectangular "de-emphasis" design, 101-tap Hann audio low-pass, pick, normalise, u8
+        std::vector<float> lpf_de = DSP::create_fir_filter<float>(64, 1.0 / (62400.0 * 75e-6), &DSP::rectangular_window);
+        std::vector<float> lpf_a = DSP::create_fir_filter<float>(101, (10000.0 / 2.0) / 62400.0, &DSP::hann_window);
+        std::vector<uint8_t> pcm = sdrhip::fm_audio_u8(x6f, lpf_de, lpf_a, 6);
+        dump(std::string(argv[2]) + ".pcm.u8", pcm);
+        dump(std::string(argv[2]) + ".lpf_de.f32", lpf_de);
+        dump(std::string(argv[2]) + ".lpf_a.f32", lpf_a);
+
         // argument checks behave like the reference (bladerf_apt_demod.cpp:254-259)
         bool threw = false;
         try { std::vector<double> bad(64, 1.0); polyphase_decimate(cf_samples, 10, bad); }

@@ -50,6 +50,15 @@ def test_reference_loop_through_shims(golden, oracle, tmp_path):
     want_filt = oracle.filter_vec(x6, [0.1, -0.2, 0.3, 0.4, 0.3, -0.2, 0.1])
     assert np.abs(filt - want_filt).max() <= 1e-6
     assert np.array_equal(filt[-3:], want_filt[-3:])              # the reference's truncated tail rows
+    # FM audio stage through the shim (bladerf_fm_demod.cpp:301-313) against the oracle chain
+    pcm = np.fromfile(pfx + ".pcm.u8", np.uint8)
+    h_de = np.fromfile(pfx + ".lpf_de.f32", np.float32)
+    h_a = np.fromfile(pfx + ".lpf_a.f32", np.float32)
+    assert h_de.size == 64 and h_a.size == 101
+    _, want_pcm = oracle.fm_audio_chain(np.fromfile(pfx + ".x6f.f32", np.float32), h_de, h_a, 6)
+    assert pcm.shape == want_pcm.shape
+    d = np.abs(pcm.astype(np.int32) - want_pcm.astype(np.int32))
+    assert d.max() <= 1 and np.count_nonzero(d) <= max(4, pcm.size // 500)
 
 
 @pytest.mark.parametrize("mode", ["fm", "env", "iq"])

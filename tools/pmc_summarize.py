@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output directories into the small files kept under profiles/.
 
-  pmc_summarize.py <tag> <stats_dir> <fetch_dir> <write_dir> [kernel-substring]
+  pmc_summarize.py <tag> <stats_dir> <fetch_dir> <write_dir> [kernel-substring [json-name]]
 
 Writes profiles/<tag>_kernel_stats.csv (copy of *_kernel_stats.csv), profiles/<tag>_pmc_hbm.csv
 (mean FETCH_SIZE / WRITE_SIZE per kernel, in the counters' KB unit) and, for the kernel whose name
@@ -20,10 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def find(d, pat):
-    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit("no %s under %s" % (pat, d))
-    return hits[0]
+    return hits[-1]                      # the newest run (gpurun_out/ accumulates)
 
 
 def counter_means(d):
@@ -39,6 +39,7 @@ def counter_means(d):
 def main():
     tag, stats, fetch, write = sys.argv[1:5]
     sub = sys.argv[5] if len(sys.argv) > 5 else "fir_"
+    jname = sys.argv[6] if len(sys.argv) > 6 else "hbm_traffic.json"
     prof = os.path.join(ROOT, "profiles")
     shutil.copy(find(stats, "*kernel_stats.csv"), os.path.join(prof, tag + "_kernel_stats.csv"))
     rows = {}
@@ -64,7 +65,7 @@ def main():
                    "kernel": k, "rocprof_avg_kernel_ns": avg_ns, "profile_tag": tag,
                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python3 bench.py, mean over "
                              "the kernel's dispatches; FETCH_SIZE doubled per the guide's gfx950 correction; KB -> bytes x1024"},
-                  open(os.path.join(prof, "hbm_traffic.json"), "w"), indent=1)
+                  open(os.path.join(prof, jname), "w"), indent=1)
         print("traffic", int(fb + wb), "avg_ns", avg_ns)
 
 

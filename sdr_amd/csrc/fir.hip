@@ -32,8 +32,10 @@
 // distinct banks.
 //
 // Numerics: float32 fmaf accumulation in ascending window order (identical for every tile
-// placement); decimation indexing is exact (output m <-> input D*m); zero pre-history (samples
-// < 0 read as 0) as the reference.  For int16 input the exact 2^-11 Q11 scale is folded into the
+// placement, except the y a tile's last discriminator output takes from successor_output(): a
+// wave-wide sum, so that one output can differ in the last bit between two tilings); decimation
+// indexing is exact (output m <-> input D*m); zero pre-history (samples < 0 read as 0) as the
+// reference.  For int16 input the exact 2^-11 Q11 scale is folded into the
 // taps.
 
 #include <cmath>

@@ -493,3 +493,39 @@ def test_fm_audio_post_chain(sdr, oracle):
             except sdr.SdrError:
                 continue
             check_linear(p.execute_host(x), y, f"real T={T} D={Dd} R={R}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nfft", [64, 512, 4096])
+def test_fft_hops_and_long_runs(sdr, oracle, nfft):
+    """hop = N/2 keeps half a frame in registers, other hops reload; with more frames than resident
+    (workgroup, slot) pairs every lane walks a run of consecutive frames and the last run is
+    ragged.  Selected frames against the oracle's float64 DFT of the same slice."""
+    rng = np.random.default_rng(nfft)
+    fpb = 4096 // nfft
+    groups = 256 * 3 * fpb                       # resident pairs on an MI355X (see launch_fft)
+    w = oracle.window("blackman", nfft)
+    for hop in (nfft // 2, nfft, nfft // 4, 3 * nfft // 4 + 1):
+        frames = 2 * groups + groups // 3 + 5    # runs of 3 frames, last workgroups partly idle
+        n = (frames - 1) * hop + nfft + 3
+        t = np.arange(n)
+        iq = np.empty(2 * n, np.int16)
+        ph = 2 * np.pi * (0.0371 * t + 2e-9 * t * t)
+        iq[0::2] = (1500 * np.cos(ph) + rng.integers(-200, 201, n)).astype(np.int16)
+        iq[1::2] = (1500 * np.sin(ph) + rng.integers(-200, 201, n)).astype(np.int16)
+        plan = sdr.FftPlan(nfft, hop, w)
+        assert plan.frame_count(n) == frames
+        got = plan.execute_host(iq).astype(np.float64)
+        assert got.shape == (frames, nfft)
+        assert np.isfinite(got).all()
+        run0 = 3 * (frames // 6)                 # first frame of a run in the middle
+        pick = sorted({0, 1, 2, 3, 4, 5, run0 - 1, run0, run0 + 1, run0 + 2, run0 + 3, frames - 7,
+                       frames - 2, frames - 1})
+        for f in pick:
+            seg = iq[2 * f * hop: 2 * (f * hop + nfft)]
+            want_db, want_lin = oracle.fft_power_db_i16(seg, nfft, hop, w, linear=True)
+            lin = 10.0 ** (got[f] / 10.0)
+            peak = want_lin.max()
+            assert np.abs(lin - want_lin[0]).max() <= 1e-5 * peak, (nfft, hop, f)
+            strong = want_lin[0] > peak * 1e-5
+            assert np.abs(got[f] - want_db[0])[strong].max() <= 1e-3, (nfft, hop, f)

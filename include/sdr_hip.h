@@ -190,6 +190,21 @@ int sdr_magnitude_i16_dev(const int16_t *d_iq, size_t n, float *d_mag, void *str
  * reference divides by zero there).  The float -> u8 conversion truncates like as(u8). */
 int sdr_audio_u8_dev(const float *d_x, size_t n, float *d_max, uint8_t *d_pcm, void *stream);
 
+/* ---- f3: APT line synchronisation and image assembly (host code, fed by the GPU chain) -----------
+ * Replaces the tail of the consumer loop, bladerf_apt_demod.cpp:756-793, with
+ * get_correlation_peaks (:181-213) and add_line_to_image (:216-246): min/max normalisation of the
+ * pending envelope samples to 0..255, sliding correlation with the 39-sample sync pulse (:563),
+ * one image row of `width` pixels per detected line, scrolling `rows` x `width` 8-bit image
+ * (reference: 2080 x 700, :565,:580), consumed samples dropped up to 500 before the last peak.
+ * push: x9 = n envelope samples (the SDR_MODE_ENV output of the second stage), *lines_added =
+ * rows appended by this call.  get: copies the image (rows*width bytes, newest line last). */
+typedef struct sdr_apt_image sdr_apt_image;
+int sdr_apt_image_create(int width, int rows, sdr_apt_image **image);
+int sdr_apt_image_destroy(sdr_apt_image *image);
+int sdr_apt_image_push(sdr_apt_image *image, const float *x9, size_t n, int *lines_added);
+int sdr_apt_image_get(const sdr_apt_image *image, uint8_t *dst, uint64_t *total_lines,
+                      size_t *pending_samples);
+
 /* ---- a2 alone: int16 -> complex float, x 1/2048 ---------------------------------------------
  * Replaces the scale loop of bladerf_sdr.h:288-291,334-337 for callers that want the float
  * stream itself. */

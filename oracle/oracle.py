@@ -399,3 +399,27 @@ def fm_audio_chain(x5, h_de, h_a, D):
                                  C.c_int(h_a.size), C.c_int(D), _d(audio),
                                  pcm.ctypes.data_as(C.c_void_p))
     return audio[:k], pcm[:k]
+
+
+class AptSync:
+    """bladerf_apt_demod.cpp:756-793 block by block (oracle state: pending samples + image)."""
+
+    def __init__(self, width=2080, rows=700, capacity=1 << 22):
+        self.width, self.rows = width, rows
+        self.x10 = np.zeros(capacity, np.float64)
+        self.n10 = C.c_size_t(0)
+        self.img = np.zeros((rows, width), np.uint8)
+        self.lines = 0
+
+    def push(self, x9):
+        x = _f64(x9)
+        peaks = np.zeros(4096, np.int64)
+        npk = C.c_int()
+        r = lib().orc_apt_sync_block(_d(self.x10), C.byref(self.n10), C.c_size_t(self.x10.size), _d(x),
+                                     C.c_size_t(x.size), self.img.ctypes.data_as(C.c_void_p),
+                                     C.c_int(self.rows), C.c_int(self.width),
+                                     peaks.ctypes.data_as(C.c_void_p), C.c_int(peaks.size), C.byref(npk))
+        if r < 0:
+            raise ValueError("AptSync: pending buffer overflow")
+        self.lines += r
+        return r, peaks[: npk.value].copy()

@@ -520,3 +520,82 @@ size_t orc_fm_audio_chain(const double *x5, size_t n, const double *h_de, int T_
     free(a); free(b);
     return m;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * f3: APT line sync + image assembly -- bladerf/apt_demod/src/bladerf_apt_demod.cpp:756-793,
+ * get_correlation_peaks :181-213, add_line_to_image :216-246, sync pulse :563.
+ * OpenCV is not in the tree: PARITY UNPINNED; restated semantics: scalar*(A - s) evaluates as
+ * A*alpha + beta in double, convertTo = cvRound (half to even) + saturate, Mat::dot sums in double.
+ * Divergences restated from the build: fewer than 39 pending samples or a constant block do
+ * nothing (the reference's unsigned loop bound wraps / it divides by zero); the drop count is
+ * max(last_peak - 500, 0) with a real clamp (the reference's unsigned max cannot clamp).
+ *
+ * One block: x10 (capacity cap10, *n10 valid) gets x9 appended, img (rows x width) gets one row
+ * per detected line, the consumed head of x10 is dropped.  peaks_out (optional, up to max_peaks
+ * entries) receives the peak positions of this block.  Returns the number of rows added, or -1
+ * when x10 would overflow. */
+static const int16_t orc_sync_pulse[39] = {-128, -128, -128, -128, 127, 127, -128, -128, 127, 127, -128,
+    -128, 127, 127, -128, -128, 127, 127, -128, -128, 127, 127, -128, -128, 127, 127, -128, -128, 127,
+    127, -128, -128, -128, -128, -128, -128, -128, -128, -128};
+
+int orc_apt_sync_block(double *x10, size_t *n10, size_t cap10, const double *x9, size_t n9,
+                       uint8_t *img, int rows, int width, long long *peaks_out, int max_peaks,
+                       int *n_peaks)
+{
+    if (n_peaks) *n_peaks = 0;
+    if (*n10 + n9 > cap10) return -1;
+    memcpy(x10 + *n10, x9, n9 * sizeof(double));
+    *n10 += n9;
+    const size_t N = *n10;
+    if (N < 39) return 0;
+    double lo = x10[0], hi = x10[0];
+    for (size_t i = 1; i < N; ++i) { if (x10[i] < lo) lo = x10[i]; if (x10[i] > hi) hi = x10[i]; }
+    const double delta = hi - lo;
+    if (!(delta > 0.0)) return 0;
+    const double alpha = 255.0 / delta, beta = -lo * alpha;
+    int16_t *x12 = (int16_t *)malloc(N * sizeof(int16_t));
+    uint8_t *x11 = (uint8_t *)malloc(N);
+    for (size_t i = 0; i < N; ++i) {
+        const double v = x10[i] * alpha + beta;
+        double s = nearbyint(v - 128.0);
+        if (s < -32768.0) s = -32768.0;
+        if (s > 32767.0) s = 32767.0;
+        x12[i] = (int16_t)s;
+        double u = nearbyint(v);
+        if (u < 0.0) u = 0.0;
+        if (u > 255.0) u = 255.0;
+        x11[i] = (uint8_t)u;
+    }
+    /* peaks: list starts as {(0, 0)} */
+    size_t pcap = N / 500 + 4, np = 1;
+    long long *ppos = (long long *)calloc(pcap, sizeof(long long));
+    double *pval = (double *)calloc(pcap, sizeof(double));
+    size_t index = 0;
+    while (index <= N - 39) {
+        double dot = 0.0;
+        for (int k = 0; k < 39; ++k) dot += (double)x12[index + k] * (double)orc_sync_pulse[k];
+        const double corr = dot / 39.0;
+        if ((long long)index - ppos[np - 1] > 2000) {
+            ppos[np] = (long long)index; pval[np] = corr; ++np;
+            index += 500;
+        } else if (corr > pval[np - 1]) {
+            ppos[np - 1] = (long long)index; pval[np - 1] = corr;
+        }
+        ++index;
+    }
+    int added = 0;
+    for (size_t j = 0; j + 1 < np; ++j) {
+        if (ppos[j] + width >= (long long)N) continue;
+        if (rows > 1) memmove(img, img + width, (size_t)width * (size_t)(rows - 1));
+        memcpy(img + (size_t)width * (size_t)(rows - 1), x11 + ppos[j], (size_t)width);
+        ++added;
+    }
+    if (n_peaks) *n_peaks = (int)np;
+    if (peaks_out) for (size_t j = 0; j < np && (int)j < max_peaks; ++j) peaks_out[j] = ppos[j];
+    long long drop = ppos[np - 1] - 500;
+    if (drop < 0) drop = 0;
+    memmove(x10, x10 + drop, (N - (size_t)drop) * sizeof(double));
+    *n10 = N - (size_t)drop;
+    free(x12); free(x11); free(ppos); free(pval);
+    return added;
+}

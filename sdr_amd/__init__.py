@@ -4,5 +4,5 @@ The product is libsdrhip.so (sdr_amd/csrc/*.hip behind include/sdr_hip.h); this 
 thin Python host side (ctypes) used by tests and bench.py.
 """
 from . import capi  # noqa: F401
-from .capi import (FirPlan, FftPlan, FirStream, DevBuf, SdrError, MODE_IQ, MODE_FM, MODE_ENV, MODE_REAL,  # noqa: F401
+from .capi import (FirPlan, FftPlan, FirStream, AptImage, DevBuf, SdrError, MODE_IQ, MODE_FM, MODE_ENV, MODE_REAL,  # noqa: F401
                    IN_I16_IQ, IN_CF32, IN_F32_REAL, IN_I16_QI, IN_I8_IQ, init, sync, window, create_fir_filter)

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDRHIP_LIB") or os.path.join(_HERE, "libsdrhip.so")   # override: kernel experiments
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "stream.hip", "lib.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "stream.hip", "apt.hip", "lib.hip")]
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 OK, EINVAL, ENOMEM, EHIP, EALIGN, ECAPACITY, ENODEV, ERANGE = range(8)
@@ -375,6 +375,38 @@ class FirStream:
     def destroy(self):
         if self.h and self.h.value:
             lib().sdr_fir_stream_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class AptImage:
+    """sdr_apt_image: line sync + scrolling image (bladerf_apt_demod.cpp:756-793)."""
+
+    def __init__(self, width=2080, rows=700):
+        self.width, self.rows = width, rows
+        self.h = C.c_void_p()
+        check(lib().sdr_apt_image_create(C.c_int(width), C.c_int(rows), C.byref(self.h)))
+
+    def push(self, x9):
+        a = np.ascontiguousarray(x9, dtype=np.float32).reshape(-1)
+        added = C.c_int()
+        check(lib().sdr_apt_image_push(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.byref(added)))
+        return added.value
+
+    def get(self):
+        img = np.empty((self.rows, self.width), np.uint8)
+        lines, pend = C.c_uint64(), C.c_size_t()
+        check(lib().sdr_apt_image_get(self.h, img.ctypes.data_as(C.c_void_p), C.byref(lines), C.byref(pend)))
+        return img, lines.value, pend.value
+
+    def destroy(self):
+        if self.h and self.h.value:
+            lib().sdr_apt_image_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -178,3 +178,72 @@ def test_wire_format_unpackers(oracle):
     b = np.array([-128, 127, 0, -1, 64, 5], np.int8)
     y = oracle.unpack_scale_i8(b)
     assert np.array_equal(y, np.array([-128 + 127j, 0 - 1j, 64 + 5j]) / 128.0)
+
+
+def _apt_envelope(n_lines, width=2080, jitter=0, seed=0):
+    """synthetic 4160 Hz APT envelope: every line starts with the 7-cycle sync A pattern (two
+    samples high, two low) on a dark porch, followed by a grey ramp and noise"""
+    rng = np.random.default_rng(seed)
+    x = []
+    for ln in range(n_lines):
+        row = 0.35 + 0.25 * np.linspace(0, 1, width) + 0.01 * rng.standard_normal(width)
+        row[:4] = 0.1
+        for c in range(7):
+            row[4 + 4 * c: 6 + 4 * c] = 0.9
+            row[6 + 4 * c: 8 + 4 * c] = 0.1
+        row[32:39] = 0.1
+        x.append(row[: width - (jitter if ln % 5 == 4 else 0)])
+    return np.concatenate(x)
+
+
+def _apt_sync_python(x10, width):
+    """independent restatement of bladerf_apt_demod.cpp:758-787 + :181-213 (numpy correlation, the
+    sequential peak logic in plain Python) -> (peak positions, image rows)"""
+    pulse = np.array([-128] * 4 + [127, 127, -128, -128] * 7 + [-128] * 7, np.float64)
+    assert pulse.size == 39
+    lo, hi = x10.min(), x10.max()
+    alpha = 255.0 / (hi - lo)
+    v = x10 * alpha + (-lo * alpha)
+    x12 = np.clip(np.rint(v - 128.0), -32768, 32767)
+    x11 = np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    corr = np.correlate(x12, pulse, mode="valid") / 39.0
+    peaks = [[0, 0.0]]
+    index = 0
+    while index <= x10.size - 39:
+        if index - peaks[-1][0] > 2000:
+            peaks.append([index, corr[index]])
+            index += 500
+        elif corr[index] > peaks[-1][1]:
+            peaks[-1] = [index, corr[index]]
+        index += 1
+    rows = [x11[p: p + width] for p, _ in peaks[:-1] if p + width < x10.size]
+    return [p for p, _ in peaks], rows
+
+
+def test_apt_line_sync_oracle(oracle):
+    """f3: the C oracle against an independent numpy/Python restatement of the same reference
+    lines (OpenCV absent -> parity unpinned), over two blocks with carried-over samples."""
+    x = _apt_envelope(12)
+    s = oracle.AptSync(rows=16)
+    added, peaks = s.push(x)
+    want_peaks, want_rows = _apt_sync_python(x, 2080)
+    assert list(peaks) == want_peaks and peaks[0] == 0
+    assert added == len(want_rows) and added >= 4
+    for k, row in enumerate(want_rows):
+        assert np.array_equal(s.img[16 - added + k], row)
+    drop = max(want_peaks[-1] - 500, 0)
+    assert s.n10.value == x.size - drop
+    # every detected line start sits on a sync pulse of the synthetic signal (multiples of 2080)
+    assert all(p % 2080 == 0 for p in peaks[:-1])
+    # second block continues with the carried-over samples
+    x2 = _apt_envelope(6, seed=1)
+    pending = np.concatenate([x[drop:], x2])
+    added2, peaks2 = s.push(x2)
+    want_peaks2, want_rows2 = _apt_sync_python(pending, 2080)
+    assert list(peaks2) == want_peaks2 and added2 == len(want_rows2)
+    for k, row in enumerate(want_rows2):
+        assert np.array_equal(s.img[16 - added2 + k], row)
+    assert s.lines == added + added2
+    # fewer than 39 samples / constant input: nothing happens
+    t = oracle.AptSync(rows=4)
+    assert t.push(np.ones(20))[0] == 0 and t.push(np.ones(5000))[0] == 0

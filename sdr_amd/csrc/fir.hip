@@ -155,6 +155,23 @@ __device__ __forceinline__ float discriminate(float2 y1, float2 y0, float scale)
     return scale * atan2_finite(im, re);
 }
 
+// Outputs are written once and never read by this kernel: non-temporal stores (the "nt" policy)
+// keep them from displacing the input stream in L2; +3 % on a bare stream of the same bytes
+// (tools/ubench/stream_read.hip).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(float *p, float a) { __builtin_nontemporal_store(a, p); }
+__device__ __forceinline__ void nt_store(float *p, float a, float b)
+{
+    v2f v = {a, b};
+    __builtin_nontemporal_store(v, (v2f *)p);
+}
+__device__ __forceinline__ void nt_store(float *p, float a, float b, float c, float d)
+{
+    v4f v = {a, b, c, d};
+    __builtin_nontemporal_store(v, (v4f *)p);
+}
+
 template <int R>
 __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict__ outv,
                                               long long ch, long long m0, const float2 (&y)[R],
@@ -165,7 +182,7 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long long j = m0 + r;
-            if (j >= g.out_begin && j < g.out_end) out[j - g.out_begin] = y[r];
+            if (j >= g.out_begin && j < g.out_end) nt_store((float *)(out + (j - g.out_begin)), y[r].x, y[r].y);
         }
         return;
     }
@@ -187,17 +204,17 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
     const bool whole = (m0 >= g.out_begin) && (m0 + R <= g.out_end);
     if (R >= 2 && whole && (((uintptr_t)dst) & (R >= 4 ? 15 : 7)) == 0) {
         if (R == 2) {
-            *(float2 *)dst = make_float2(v[0], v[1]);
+            nt_store(dst, v[0], v[1]);
         } else {
 #pragma unroll
             for (int r = 0; r < R; r += 4)
-                *(float4 *)(dst + r) = make_float4(v[r], v[(r + 1) % R], v[(r + 2) % R], v[(r + 3) % R]);
+                nt_store(dst + r, v[r], v[(r + 1) % R], v[(r + 2) % R], v[(r + 3) % R]);
         }
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long long j = m0 + r;
-            if (j >= g.out_begin && j < g.out_end) dst[r] = v[r];
+            if (j >= g.out_begin && j < g.out_end) nt_store(dst + r, v[r]);
         }
     }
 }

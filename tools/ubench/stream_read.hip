@@ -83,6 +83,70 @@ __global__ void __launch_bounds__(256) read_tiles_v(const uint4 *in, float *out,
     }
 }
 
+// store policy variants of the 20 KB tile kernel: 0 = no stores at all, 1 = non-temporal stores,
+// 2 = one wave of the workgroup stores the whole 2 KB row (dwordx4 per lane)
+template <int POLICY>
+__global__ void __launch_bounds__(256) read_tiles_store(const uint4 *in, float *out, size_t n16)
+{
+    __shared__ float row[512];
+    const size_t tile = (size_t)(blockIdx.x & 7) * (gridDim.x / 8) + (blockIdx.x >> 3);
+    const size_t base = tile * 1280;
+    unsigned acc = 0;
+    uint4 a[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a[k] = in[base + k * 256 + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w;
+    const float v = __uint_as_float(acc);
+    if (POLICY == 0) {
+        if (acc == 0x12345678u) out[tile] = v;
+    } else if (POLICY == 5) {          // same bytes, 8x larger bursts: every 8th tile writes 16 KB
+        if ((tile & 7) == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ((float2 *)out)[(tile + j) * 256 + threadIdx.x] = make_float2(v, 1.f);
+        } else if (acc == 0x12345678u) out[tile] = v;
+    } else if (POLICY == 6 || POLICY == 7 || POLICY == 8) {      // cache-policy bits on the store
+        float2 *p = (float2 *)out + tile * 256 + threadIdx.x;
+        const float2 val = make_float2(v, 1.f);
+        if (POLICY == 6) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(val) : "memory");
+        if (POLICY == 7) asm volatile("global_store_dwordx2 %0, %1, off nt sc0 sc1" ::"v"(p), "v"(val) : "memory");
+        if (POLICY == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(val) : "memory");
+    } else if (POLICY == 3) {          // stores that stay in L2: every workgroup of an XCD rewrites the same 2 KB
+        ((float2 *)out)[(size_t)(blockIdx.x & 7) * 4096 + threadIdx.x] = make_float2(v, 1.f);
+    } else if (POLICY == 4) {          // same bytes to HBM, but a 64 KB-strided (scattered) destination
+        ((float2 *)out)[((tile * 37) % (gridDim.x)) * 256 + threadIdx.x] = make_float2(v, 1.f);
+    } else if (POLICY == 1) {
+        float *p = out + (tile * 256 + threadIdx.x) * 2;
+        __builtin_nontemporal_store(v, p);
+        __builtin_nontemporal_store(1.f, p + 1);
+    } else {
+        row[2 * threadIdx.x] = v; row[2 * threadIdx.x + 1] = 1.f;
+        __syncthreads();
+        if (threadIdx.x < 128) ((float4 *)out)[tile * 128 + threadIdx.x] = ((float4 *)row)[threadIdx.x];
+    }
+}
+
+// K consecutive 20 KB tiles per workgroup, one after the other: the store of tile k is in flight
+// while tile k+1 is fetched, so only the last store's acknowledge holds the workgroup's slot
+template <int K, bool NT>
+__global__ void __launch_bounds__(256) read_tiles_seq(const uint4 *in, float *out, size_t n16)
+{
+    const size_t grp = (size_t)(blockIdx.x & 7) * (gridDim.x / 8) + (blockIdx.x >> 3);
+    for (int t = 0; t < K; ++t) {
+        const size_t tile = grp * K + t;
+        const size_t base = tile * 1280;
+        unsigned acc = 0;
+        uint4 a[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a[k] = in[base + k * 256 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w;
+        float *p = out + (tile * 256 + threadIdx.x) * 2;
+        if (NT) { __builtin_nontemporal_store(__uint_as_float(acc), p); __builtin_nontemporal_store(1.f, p + 1); }
+        else *(float2 *)p = make_float2(__uint_as_float(acc), 1.f);
+    }
+}
+
 int main()
 {
     const size_t n = (size_t)1 << 30;          // samples, 4 B each
@@ -93,7 +157,8 @@ int main()
     hipMemset(in, 1, n * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double bytes = 4.4 * (double)n;
-    for (int variant = 0; variant < 9; ++variant) {
+    for (int variant = 9; variant < 22; ++variant) {
+        if (variant >= 11 && variant <= 15) continue;
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(e0);
@@ -106,13 +171,26 @@ int main()
                 if (variant == 5) read_tiles_v<5, true, false><<<(unsigned)(n16 / 1280), 256>>>(in, out, n16);
                 if (variant == 6) read_tiles_v<5, false, true><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
                 if (variant == 7) read_tiles_v<20, false, false><<<(unsigned)(n16 / 5120), 256>>>(in, out, n16);
+                if (variant == 9) read_tiles_store<0><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 10) read_tiles_store<1><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 11) read_tiles_store<2><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 12) read_tiles_seq<2, false><<<(unsigned)(n16 / 1280 / 2) & ~7u, 256>>>(in, out, n16);
+                if (variant == 13) read_tiles_seq<4, false><<<(unsigned)(n16 / 1280 / 4) & ~7u, 256>>>(in, out, n16);
+                if (variant == 14) read_tiles_seq<8, false><<<(unsigned)(n16 / 1280 / 8) & ~7u, 256>>>(in, out, n16);
+                if (variant == 15) read_tiles_seq<4, true><<<(unsigned)(n16 / 1280 / 4) & ~7u, 256>>>(in, out, n16);
+                if (variant == 16) read_tiles_store<3><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 17) read_tiles_store<4><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 18) read_tiles_store<5><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 19) read_tiles_store<6><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 20) read_tiles_store<7><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 21) read_tiles_store<8><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
                 if (variant == 8) read_tiles_v<10, true, true><<<(unsigned)(n16 / 2560) & ~7u, 256>>>(in, out, n16);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
             if (rep && ms < best) best = ms;
         }
-        const char *nm[9] = {"grid-stride 8 wg/CU", "grid-stride 32 wg/CU", "20 KB tile per wg, vector loads", "20 KB tile per wg, LDS-DMA", "40 KB tile", "20 KB tile, nontemporal", "20 KB tile, XCD-contiguous", "80 KB tile", "40 KB nontemporal XCD-contiguous"};
+        const char *nm[22] = {"grid-stride 8 wg/CU", "grid-stride 32 wg/CU", "20 KB tile per wg, vector loads", "20 KB tile per wg, LDS-DMA", "40 KB tile", "20 KB tile, nontemporal", "20 KB tile, XCD-contiguous", "80 KB tile", "40 KB nontemporal XCD-contiguous", "20 KB XCD-contiguous, NO stores", "20 KB XCD-contiguous, nontemporal stores", "20 KB XCD-contiguous, dwordx4 stores from 2 waves", "2 tiles in sequence per wg", "4 tiles in sequence per wg", "8 tiles in sequence per wg", "4 tiles in sequence, nontemporal stores", "stores that stay in L2 (same 2 KB per XCD)", "stores to a permuted tile order", "every 8th tile stores 16 KB", "stores sc0 sc1", "stores nt sc0 sc1", "stores sc1"};
         printf("%-34s %.4f ms  %.0f GB/s (4.4 B/sample)\n", nm[variant], best, bytes / best / 1e6);
     }
     return 0;

@@ -574,9 +574,11 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     if (interior) {
         const uint32_t *wsrc = src + W0;
         for (int k = 0; k < g.n_inst; ++k) {
-            int sg = sample_granule(g, k * NT + tid);
+            const int a = k * NT + tid;
+            int sg = sample_granule(g, a);
             sg = sg < g.s_gran ? sg : 0;
-            dma16(wsrc + 4 * sg, __builtin_amdgcn_readfirstlane(lds_addr(lds4 + k * NT + (tid & ~63))));
+            if (a < g.a_gran)              // last round: lanes past the image stay masked
+                dma16(wsrc + 4 * sg, __builtin_amdgcn_readfirstlane(lds_addr(lds4 + k * NT + (tid & ~63))));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -589,7 +591,7 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 const long long si = s + u;
                 w[u] = (si >= g.lo_valid && si < g.hi_valid) ? src[si] : 0u;
             }
-            lds4[a] = make_uint4(w[0], w[1], w[2], w[3]);
+            if (a < g.a_gran) lds4[a] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
     __syncthreads();
@@ -766,8 +768,8 @@ fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         }
 #pragma unroll
         for (int k = 0; k < kPlanarSlots; ++k) {
-            if (k0 + k < g.n_inst) {
-                const int a = (k0 + k) * NT + tid;
+            const int a = (k0 + k) * NT + tid;
+            if (k0 + k < g.n_inst && a < g.a_gran) {
                 re4[a] = make_float4(lo16(w[k].x), lo16(w[k].y), lo16(w[k].z), lo16(w[k].w));
                 im4[a] = make_float4(hi16(w[k].x), hi16(w[k].y), hi16(w[k].z), hi16(w[k].w));
             }
@@ -840,8 +842,11 @@ bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *
     if (s_tile > (1LL << 22)) return false;
     o->s_gran = (int)((s_tile + spg - 1) / spg);
     const int a = o->s_gran + (o->pad ? o->s_gran / o->q + 1 : 0);
-    o->a_gran = roundup(a, NT);
-    o->n_inst = o->a_gran / NT;
+    // the persistent streaming kernel stages whole rounds of NT granules; the one-tile kernels
+    // mask the last round, so their image is exact (64 taps / 10: 22.8 KB, a seventh workgroup
+    // per CU fits in the 160 KB)
+    o->a_gran = stream ? roundup(a, NT) : a;
+    o->n_inst = (o->a_gran + NT - 1) / NT;
     o->lds_bytes = o->a_gran * (planar ? 32 : 16) + (NT + 2) * 8 + (stream ? roundup(T, 4) * 4 : 0);
     return true;
 }

@@ -21,7 +21,7 @@
 // Two kernels share that scheme:
 //   fir_raw_kernel     (automatic choice for int16 input without mixer) keeps the RAW int16 pairs
 //       in LDS, filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), and converts
-//       after each LDS read.  Half the LDS footprint: 6 workgroups per CU on the headline shape.
+//       after each LDS read.  Half the LDS footprint: 7 workgroups per CU on the headline shape.
 //   fir_stream_kernel  keeps FLOAT samples in LDS: persistent workgroups fetch the raw tile k+1
 //       from HBM into registers while they walk tile k, then convert it ONCE per sample
 //       (int16 -> f32 is a half-rate VALU op on gfx950, and a sample is read by ~4 lanes), apply
@@ -968,7 +968,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     // Long filters (>= 32 MACs per input sample) are bound by VALU issue and, sustained, by the
     // power the conversions burn: the planar kernel converts once and runs T = 511 / D = 10 27 %
     // faster when the chip is warm (0.230 vs 0.292 ms per 2^26 samples); short filters are bound
-    // by the HBM stream and want the raw tile's six workgroups per CU.
+    // by the HBM stream and want the raw tile's seven workgroups per CU.
     const bool planar = (d->pipeline == 3) || (d->pipeline == 0 && raw_possible && d->n_taps >= 32 * d->decim);
 
     // ---- choose kernel, outputs per lane (R) and workgroup size (NT) ------------------------

@@ -241,6 +241,10 @@ int sdr_fir_stream_create(sdr_fir_plan *plan, size_t max_block_samples, sdr_fir_
 int sdr_fir_stream_destroy(sdr_fir_stream *stream);
 int sdr_fir_stream_push(sdr_fir_stream *stream, const void *block_host, size_t n_samples);
 int sdr_fir_stream_pop(sdr_fir_stream *stream, void *out_host, size_t capacity, size_t *n_out);
+/* Zero-copy variant of push: *buffer = the pinned host buffer (max_block_samples long) of the slot
+ * the next push will use -- the counterpart of handing iq_data_queue[write_index] to
+ * bladerf_sync_rx (bladerf_apt_demod.cpp:166).  Fill it, then push that same pointer. */
+int sdr_fir_stream_next_buffer(sdr_fir_stream *stream, void **buffer);
 /* File replay source.  Replaces temp_get_data (bladerf/apt_demod/src/bladerf_apt_demod.cpp:92-148):
  * the raw sample file at `path` (samples of the plan's input kind, e.g. a .sc16 recording) is cut
  * to a multiple of two blocks (:113-117) and pushed block by block, `passes` times over (the

@@ -347,6 +347,16 @@ class FirStream:
         a, n = self.plan._in_array(block)
         check(lib().sdr_fir_stream_push(self.h, a.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
 
+    def next_buffer(self, dtype, count):
+        """numpy view of the pinned staging buffer the next push will use (zero-copy hand-off)"""
+        ptr = C.c_void_p()
+        check(lib().sdr_fir_stream_next_buffer(self.h, C.byref(ptr)))
+        n = count * np.dtype(dtype).itemsize
+        return np.frombuffer((C.c_char * n).from_address(ptr.value), dtype=dtype, count=count)
+
+    def push_buffer(self, buf, n_samples):
+        check(lib().sdr_fir_stream_push(self.h, C.c_void_p(buf.ctypes.data), C.c_size_t(n_samples)))
+
     def pop(self):
         out = np.empty(self._cap, self.plan.out_dtype)
         n = C.c_size_t()

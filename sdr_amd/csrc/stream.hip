@@ -89,6 +89,19 @@ extern "C" int sdr_fir_stream_destroy(sdr_fir_stream *s)
     return SDR_OK;
 }
 
+// The pinned staging buffer of the slot the next push will use, max_block samples long: a capture
+// thread can let the radio write straight into it (what bladerf_sync_rx does with
+// iq_data_queue[write_index], bladerf_apt_demod.cpp:166) and push that pointer, which skips the
+// host-side copy.  SDR_ECAPACITY while that slot is still in flight.
+extern "C" int sdr_fir_stream_next_buffer(sdr_fir_stream *s, void **buffer)
+{
+    if (!s || !buffer) { sdr::set_error("bad argument"); return SDR_EINVAL; }
+    *buffer = nullptr;
+    if (s->busy[s->head]) { sdr::set_error("both slots in flight: pop before taking a buffer"); return SDR_ECAPACITY; }
+    *buffer = s->h_in[s->head];
+    return SDR_OK;
+}
+
 // Enqueue one block.  Returns SDR_ECAPACITY when both slots are still waiting to be popped.
 extern "C" int sdr_fir_stream_push(sdr_fir_stream *s, const void *block, size_t n)
 {
@@ -105,7 +118,7 @@ extern "C" int sdr_fir_stream_push(sdr_fir_stream *s, const void *block, size_t 
         SDR_HIP(hipMemcpyAsync(s->d_win[k], (const unsigned char *)s->d_win[s->prev_slot] + (s->prev_len - h) * ib,
                                h * ib, hipMemcpyDeviceToDevice, s->st));
     }
-    memcpy(s->h_in[k], block, n * ib);
+    if (block != s->h_in[k]) memcpy(s->h_in[k], block, n * ib);      // not already in the slot's buffer
     SDR_HIP(hipMemcpyAsync((unsigned char *)s->d_win[k] + h * ib, s->h_in[k], n * ib, hipMemcpyHostToDevice, s->st));
     const unsigned long long n_total = s->n_pushed + n;
     const unsigned long long first = s->n_pushed - h;            // stream index of d_win[k][0]

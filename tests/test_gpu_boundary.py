@@ -178,3 +178,34 @@ def test_apt_image_from_gpu_chain(sdr, oracle):
     # argument errors
     with pytest.raises(sdr.SdrError):
         sdr.AptImage(0, 10)
+
+
+def test_stream_zero_copy_buffers(sdr, oracle):
+    """a12: the producer fills the slot's pinned buffer in place (iq_data_queue[write_index] handed
+    to bladerf_sync_rx, bladerf_apt_demod.cpp:166) and pushes that pointer: same result as the
+    copying push, and a third buffer is refused while both slots are in flight."""
+    rng = np.random.default_rng(9)
+    blk, nblk, D, T = 50_000, 5, 10, 64
+    h = oracle.create_fir_filter(T, 0.09, "hann")
+    iq = oracle.synth_fm_i16(blk * nblk, fs=1.0e6, ftone=900.0, dev=20000.0, amp=1700.0)
+    iq = (iq + rng.integers(-25, 26, iq.size)).astype(np.int16)
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_ENV)
+    want = plan.execute_host(iq)
+    stream = sdr.FirStream(plan, blk)
+    parts = []
+    for b in range(nblk):
+        buf = stream.next_buffer(np.int16, 2 * blk)
+        buf[:] = iq[2 * b * blk: 2 * (b + 1) * blk]
+        stream.push_buffer(buf, blk)
+        if b >= 1:
+            parts.append(stream.pop())
+        if b == 0:
+            b2 = stream.next_buffer(np.int16, 2 * blk)        # second slot is free
+            assert b2.ctypes.data != buf.ctypes.data
+    parts.append(stream.pop())
+    got = np.concatenate(parts)
+    assert np.array_equal(got, want)
+    stream.push(iq[: 2 * blk]); stream.push(iq[: 2 * blk])
+    with pytest.raises(sdr.SdrError) as e:
+        stream.next_buffer(np.int16, 2 * blk)
+    assert e.value.status == sdr.capi.ECAPACITY

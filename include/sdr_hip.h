@@ -116,7 +116,9 @@ typedef struct sdr_fir_desc {
                              2 = float tiles converted once, persistent workgroups that prefetch
                              the next tile into registers (any input);
                              3 = int16 converted once while staging into two float planes in LDS,
-                             one tile per workgroup (int16 input without mixer only) */
+                             one tile per workgroup (int16 input without mixer only);
+                             4 = the same float planes, window walk as a Toeplitz GEMM on the
+                             matrix cores in float32 (long filters; int16 without mixer only) */
 } sdr_fir_desc;
 
 /* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument
@@ -129,7 +131,7 @@ size_t sdr_fir_out_count(const sdr_fir_plan *plan, size_t n_in);
 /* what the plan chose: outputs per lane, threads per workgroup, LDS bytes per workgroup */
 int sdr_fir_plan_info(const sdr_fir_plan *plan, int *outputs_per_lane, int *threads,
                       int *lds_bytes);
-/* which kernel the plan runs: 1 = raw-tile, 2 = streaming, 3 = planar kernel (see `pipeline`) */
+/* which kernel the plan runs: 1 = raw-tile, 2 = streaming, 3 = planar, 4 = MFMA (see `pipeline`) */
 int sdr_fir_plan_kernel(const sdr_fir_plan *plan);
 
 /* One block from zero pre-history, host buffers.  Replaces, fused in one pass,

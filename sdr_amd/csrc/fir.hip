@@ -726,23 +726,11 @@ __device__ __forceinline__ float2 successor_planar(const FirGeom &g, const float
 
 constexpr int kPlanarSlots = 8;     // granules one lane stages per round of loads
 
-template <int R>
-__global__ void __launch_bounds__(256)
-fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
-                  const float *__restrict__ gtab, const float *__restrict__ taps, const FirGeom g)
+// Stage one tile as two float planes: every lane fetches its granules (4 int16 pairs each), converts
+// them once and writes I and Q to re4[] / im4[].
+__device__ __forceinline__ void stage_planar(const FirGeom &g, const uint32_t *__restrict__ src,
+                                             long long W0, float4 *re4, float4 *im4, int tid, int NT)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *re4 = (float4 *)smem;
-    float4 *im4 = re4 + g.a_gran;
-    const int tid = threadIdx.x;
-    const int NT = blockDim.x;
-    const long long ch = blockIdx.y;
-    const int tile = xcd_tile(g);
-    if (tile >= g.tiles_per_ch) return;
-    const long long M0 = g.tile0 + (long long)tile * (NT * R);
-    const long long W0 = M0 * g.D - g.Tback;                 // first staged sample (multiple of 4)
-    const uint32_t *src = in + ch * g.in_stride;             // sample 0 of this channel
-
     const bool interior = (W0 >= g.lo_valid) && (W0 + 4LL * g.s_gran <= g.hi_valid);
     for (int k0 = 0; k0 < g.n_inst; k0 += kPlanarSlots) {
         uint4 w[kPlanarSlots];
@@ -775,6 +763,26 @@ fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             }
         }
     }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
+                  const float *__restrict__ gtab, const float *__restrict__ taps, const FirGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *re4 = (float4 *)smem;
+    float4 *im4 = re4 + g.a_gran;
+    const int tid = threadIdx.x;
+    const int NT = blockDim.x;
+    const long long ch = blockIdx.y;
+    const int tile = xcd_tile(g);
+    if (tile >= g.tiles_per_ch) return;
+    const long long M0 = g.tile0 + (long long)tile * (NT * R);
+    const long long W0 = M0 * g.D - g.Tback;                 // first staged sample (multiple of 4)
+    const uint32_t *src = in + ch * g.in_stride;             // sample 0 of this channel
+
+    stage_planar(g, src, W0, re4, im4, tid, NT);
     __syncthreads();
     if (g.swap_iq) { float4 *t = re4; re4 = im4; im4 = t; }      // Q-first input
 
@@ -797,6 +805,93 @@ fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     store_outputs<R>(g, outv, ch, m0, acc, ynext);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fir_mfma_kernel: long filters as a Toeplitz GEMM on the matrix cores, full float32
+// (v_mfma_f32_16x16x4_f32).  Same planar float tile as fir_planar_kernel; the window walk becomes
+//   Y[i][j] = sum_k H[i][k] * X[k][j],     H[i][k] = h[D*i + Tb - k]   (Toeplitz, 16 x W)
+// with i = output within a group of 16 consecutive outputs, j = (group, component): 8 groups x
+// {I, Q} per wave, k = offset in the group's window (W = Tb + 15*D + 1 rounded up to 16).  A wave
+// owns 128 outputs, a 256-lane workgroup 512.  The useful fraction of the MACs is T / W (511 taps /
+// 10: 76 %).  One k-chunk of 16 is four MFMAs whose operands are one 16-byte read each: lane
+// (j, kq) takes samples 16q + 4kq + 0..3 of its column from LDS and lane (i, kq) the four taps that
+// go with them from a table laid out for exactly this (atab, global memory, L1/L2 resident).
+// Accumulators go through LDS (ybuf) to the common epilogue, which wants outputs 2*tid, 2*tid+1.
+// LDS: [I plane | Q plane | ybuf (513 float2)].
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMfmaAhead = 4;      // operand prefetch distance, in k-chunks of 16
+
+__global__ void __launch_bounds__(256)
+fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
+                const float4 *__restrict__ atab, const float *__restrict__ taps, const FirGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *re4 = (float4 *)smem;
+    float4 *im4 = re4 + g.a_gran;
+    float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 32);
+    const int tid = threadIdx.x;
+    constexpr int NT = 256, R = 2;
+    const long long ch = blockIdx.y;
+    const int tile = xcd_tile(g);
+    if (tile >= g.tiles_per_ch) return;
+    const long long M0 = g.tile0 + (long long)tile * (NT * R);
+    const long long W0 = M0 * g.D - g.Tback;
+    const uint32_t *src = in + ch * g.in_stride;
+    stage_planar(g, src, W0, re4, im4, tid, NT);
+    __syncthreads();
+    if (g.swap_iq) { float4 *t = re4; re4 = im4; im4 = t; }
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, kq = lane >> 4;
+    const int grp = 8 * wave + (j >> 1);                   // group of 16 outputs within the tile
+    const float *plane = (j & 1) ? (const float *)im4 : (const float *)re4;
+    const float4 *bsrc = (const float4 *)(plane + g.D * 16 * grp + 4 * kq);
+    const float4 *asrc = atab + lane;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // Operands are requested kMfmaAhead chunks (4 MFMAs = 128 cycles each) before they are used:
+    // the tap table comes from L2 at several hundred cycles, the samples from LDS.  The host pads
+    // the chunk count to a multiple of kMfmaAhead and both sources by kMfmaAhead zero chunks.
+    const int nq = g.ngran;
+    float4 a[kMfmaAhead], b[kMfmaAhead];
+#pragma unroll
+    for (int u = 0; u < kMfmaAhead; ++u) { a[u] = asrc[64 * u]; b[u] = bsrc[4 * u]; }
+    for (int q = 0; q < nq; q += kMfmaAhead) {
+#pragma unroll
+        for (int u = 0; u < kMfmaAhead; ++u) {
+            // "use" the oldest operand set so that hipcc waits for it here (counted vmcnt/lgkmcnt),
+            // then request the set kMfmaAhead chunks ahead into the same slot, then multiply; the
+            // sched_barriers keep hipcc from sinking the loads next to their use
+            const float4 av = a[u], bv = b[u];
+            asm volatile("" ::"v"(av.x), "v"(av.y), "v"(av.z), "v"(av.w), "v"(bv.x), "v"(bv.y), "v"(bv.z), "v"(bv.w));
+            __builtin_amdgcn_sched_barrier(0);
+            a[u] = asrc[64 * (q + kMfmaAhead + u)];
+            b[u] = bsrc[4 * (q + kMfmaAhead + u)];
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // lane (j, kq) holds component j&1 of outputs 4*kq + v of its group
+    {
+        float *yb = (float *)ybuf + 2 * (16 * grp + 4 * kq) + (j & 1);
+        yb[0] = acc0[0] + acc1[0];
+        yb[2] = acc0[1] + acc1[1];
+        yb[4] = acc0[2] + acc1[2];
+        yb[6] = acc0[3] + acc1[3];
+    }
+    if (g.mode == SDR_MODE_FM && tid < 64) {
+        const float2 ys = successor_planar(g, (const float *)re4, (const float *)im4, taps, tid, NT, R);
+        if (tid == 0) ybuf[NT * R] = ys;
+    }
+    __syncthreads();
+    const float2 y[R] = {ybuf[2 * tid], ybuf[2 * tid + 1]};
+    const float2 ynext = ybuf[2 * tid + 2];                // FM only; slot 512 is the successor
+    store_outputs<R>(g, outv, ch, M0 + 2LL * tid, y, ynext);
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -806,6 +901,8 @@ struct sdr_fir_plan {
     int input, mode, D, T, R, NT;
     bool raw;               // raw-tile geometry (4 samples per granule): fir_raw_kernel or fir_planar_kernel
     bool planar = false;    // fir_planar_kernel (float planes, convert once)
+    bool mfma = false;      // fir_mfma_kernel (float planes, Toeplitz GEMM on the matrix cores)
+    float4 *d_atab = nullptr;   // its A-operand table
     double scale, mix_fr;
     int spg;                // samples per LDS granule: 4 (raw) / 2 (stream)
     int Tback, Lw4, ngran, q, pad, s_gran, a_gran, n_inst, lds_bytes;
@@ -858,6 +955,14 @@ template <int R>
 hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void *out,
                     const FirGeom &g, unsigned tiles, unsigned n_ch)
 {
+    if (p->mfma) {
+        if (p->lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)fir_mfma_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+        fir_mfma_kernel<<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), 256, p->lds_bytes, st>>>(
+            (const uint32_t *)in, out, p->d_atab, p->d_taps, g);
+        return hipGetLastError();
+    }
     if (p->planar) {
         if (p->lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)fir_planar_kernel<R>,
@@ -955,7 +1060,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->n_taps > 16384) { sdr::set_error("n_taps > 16384 unsupported"); return SDR_EINVAL; }
     if (d->input < SDR_IN_I16_IQ || d->input > SDR_IN_I8_IQ) { sdr::set_error("bad input kind"); return SDR_EINVAL; }
     if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_REAL) { sdr::set_error("bad mode"); return SDR_EINVAL; }
-    if (d->pipeline < 0 || d->pipeline > 3) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
+    if (d->pipeline < 0 || d->pipeline > 4) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
 
@@ -964,7 +1069,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     p->scale = d->scale; p->mix_fr = d->mix_fr;
     (void)hipGetDevice(&p->device);
     const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0);
-    if ((d->pipeline == 1 || d->pipeline == 3) && !raw_possible) { delete p; sdr::set_error("pipeline 1 and 3 need int16 input without mixer"); return SDR_EINVAL; }
+    if ((d->pipeline == 1 || d->pipeline == 3 || d->pipeline == 4) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3 and 4 need int16 input without mixer"); return SDR_EINVAL; }
     // Long filters (>= 32 MACs per input sample) are bound by VALU issue and, sustained, by the
     // power the conversions burn: the planar kernel converts once and runs T = 511 / D = 10 27 %
     // faster when the chip is warm (0.230 vs 0.292 ms per 2^26 samples); short filters are bound
@@ -985,7 +1090,28 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     int bestR = 0, bestNT = 0;
     bool best_raw = false;
     double best_cost = 0;
-    if (raw_possible && d->pipeline != 2) {
+    if (d->pipeline == 4) {
+        // Toeplitz GEMM geometry: 256 lanes, 512 outputs per tile, groups of 16 outputs
+        if (d->outputs_per_lane && d->outputs_per_lane != 2) { delete p; sdr::set_error("pipeline 4 has 2 outputs per lane"); return SDR_EINVAL; }
+        if (d->threads && d->threads != 256) { delete p; sdr::set_error("pipeline 4 has 256 threads"); return SDR_EINVAL; }
+        Geometry gm{};
+        gm.Tback = roundup(p->T - 1, 4);
+        const int W = roundup(gm.Tback + 15 * p->D + 1, 16);
+        const int nq = roundup(W / 16, kMfmaAhead);
+        gm.ngran = nq;                                      // k-chunks of 16
+        const long long s_a = (long long)p->D * 16 * 31 + 16LL * (nq + kMfmaAhead);   // last group + look-ahead chunks
+        const long long s_b = (long long)gm.Tback + (long long)p->D * 512 + 1;  // the discriminator's successor
+        const long long s_tile = s_a > s_b ? s_a : s_b;
+        gm.s_gran = (int)((s_tile + 3) / 4);
+        gm.a_gran = gm.s_gran;
+        gm.n_inst = (gm.a_gran + 255) / 256;
+        gm.q = 1; gm.pad = 0;
+        gm.lds_bytes = gm.a_gran * 32 + 513 * 8 + 8;
+        if (gm.lds_bytes > 160 * 1024) { delete p; sdr::set_error("pipeline 4: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); return SDR_EINVAL; }
+        best = gm; bestR = 2; bestNT = 256; best_raw = true;
+        p->mfma = true;
+    }
+    if (!bestR && raw_possible && d->pipeline != 2) {
         const int pref_small[4] = {4, 2, 1, 8}, pref_large[4] = {2, 4, 1, 8};
         const int *pref = (p->D * 2 >= 16) ? pref_large : pref_small;
         for (int ri = 0; ri < 4 && !bestR; ++ri) {
@@ -1039,7 +1165,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                        d->decim, d->n_taps, d->outputs_per_lane, d->threads, d->pipeline);
         return SDR_EINVAL;
     }
-    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar; p->spg = best_raw ? 4 : 2;
+    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma; p->spg = best_raw ? 4 : 2;
     p->Tback = best.Tback; p->Lw4 = best.Lw4; p->ngran = best.ngran; p->q = best.q; p->pad = best.pad;
     p->s_gran = best.s_gran; p->a_gran = best.a_gran; p->n_inst = best.n_inst; p->lds_bytes = best.lds_bytes;
     {
@@ -1069,7 +1195,24 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             const long long i = (long long)p->D * r + p->Tback - (long long)j;
             if (i >= 0 && i < p->T) gt[j * p->R + r] = hf[i];
         }
+    std::vector<float4> at;
+    if (p->mfma) {
+        // atab[q][lane]: the four taps lane (i = lane % 16, kq = lane / 16) multiplies with window
+        // samples 16q + 4kq + 0..3 of its group: H[i][k] = h[D*i + Tb - k]; zero look-ahead chunks at the end
+        at.assign((size_t)(best.ngran + kMfmaAhead) * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int q = 0; q < best.ngran; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                float v[4];
+                for (int c = 0; c < 4; ++c) {
+                    const long long t = (long long)p->D * (lane & 15) + p->Tback - (16LL * q + 4 * (lane >> 4) + c);
+                    v[c] = (t >= 0 && t < p->T) ? hf[t] : 0.0f;
+                }
+                at[(size_t)q * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
+    if (e == hipSuccess && p->mfma) e = hipMalloc((void **)&p->d_atab, at.size() * sizeof(float4));
+    if (e == hipSuccess && p->mfma) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_taps, hf.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_gtab, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_taps, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -1085,6 +1228,7 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
 {
     if (!p) return SDR_OK;
     if (p->d_gtab) (void)hipFree(p->d_gtab);
+    if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
@@ -1118,7 +1262,7 @@ extern "C" int sdr_fir_plan_shape(const sdr_fir_plan *p, int *input, int *mode, 
 
 extern "C" int sdr_fir_plan_kernel(const sdr_fir_plan *p)
 {
-    return p ? (p->planar ? 3 : (p->raw ? 1 : 2)) : 0;
+    return p ? (p->mfma ? 4 : (p->planar ? 3 : (p->raw ? 1 : 2))) : 0;
 }
 
 extern "C" int sdr_fir_execute_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, void *d_out,

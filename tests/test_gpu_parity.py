@@ -176,7 +176,7 @@ def test_geometries_against_oracle(sdr, oracle, T, D):
     ran = 0
     for R in (1, 2, 4, 8):
         for NT in (64, 128, 256):
-            for pipe in (1, 2, 3):   # raw tile / persistent float tiles / planar float tile
+            for pipe in (1, 2, 3, 4):   # raw tile / persistent float tiles / planar float tile / MFMA
                 try:
                     p_fm = sdr.FirPlan(h, D, mode=sdr.MODE_FM, outputs_per_lane=R, threads=NT,
                                        pipeline=pipe)
@@ -399,7 +399,7 @@ def test_wire_formats(sdr, oracle):
     fm = oracle.chain_i16(iq, D, h, oracle.MODE_FM)
     env = oracle.chain_i16(iq, D, h, oracle.MODE_ENV)
     assert np.array_equal(oracle.unpack_scale_i16_qi(qi), oracle.unpack_scale_i16(iq))
-    for pipe in (1, 2, 3):
+    for pipe in (1, 2, 3, 4):
         tag = f"QI pipe={pipe}"
         check_fm(sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I16_QI, pipeline=pipe).execute_host(qi),
                  fm, y, 1 / TWO_PI, tag)

@@ -114,6 +114,16 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Exchange point of one frame.  Up to N = 1024 a frame's N/16 lanes sit in one wavefront, whose LDS
+// operations execute in order: draining lgkmcnt is all the synchronisation the exchange needs (a
+// wavefront-local shuffle through LDS); larger frames span the workgroup's waves and take the barrier.
+template <int TPF>
+__device__ __forceinline__ void frame_sync()
+{
+    if constexpr (TPF <= 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else lds_barrier();
+}
+
 struct FftGeom {
     long long n_in;      // samples available
     long long frames;    // frames to compute
@@ -254,7 +264,7 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
         dft<16>(x);
 #pragma unroll
         for (int t = 0; t < 16; ++t) lds[pidx(tl * 16 + t)] = x[t];
-        lds_barrier();  
+        frame_sync<TPF>();  
 
         float *row = live ? out + f * N : g.dummy;
         // ---- pass 2: radix R2, Ns = 16 ------------------------------------------------------
@@ -276,9 +286,9 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
 #pragma unroll
                 for (int t = 0; t < R2; ++t) emit_db<N>(row, base + t * 16, y[i][t]);
             }
-            lds_barrier();                 // the slot's image is free for the next frame
+            frame_sync<TPF>();                 // the slot's image is free for the next frame
         } else {
-            lds_barrier();                 // every lane has gathered its pass-2 inputs
+            frame_sync<TPF>();                 // every lane has gathered its pass-2 inputs
 #pragma unroll
             for (int i = 0; i < B2; ++i) {
                 const int j = tl + i * TPF;
@@ -286,7 +296,7 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
 #pragma unroll
                 for (int t = 0; t < R2; ++t) lds[pidx(base + t * 16)] = y[i][t];
             }
-            lds_barrier();  
+            frame_sync<TPF>();  
             // ---- pass 3: radix R3, Ns = 16*R2 ---------------------------------------------
 #pragma unroll
             for (int i = 0; i < B3; ++i) {
@@ -297,7 +307,7 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
 #pragma unroll
                 for (int t = 0; t < R3; ++t) emit_db<N>(row, base + t * Ns3, z[t]);
             }
-            lds_barrier();                 // the slot's image is free for the next frame
+            frame_sync<TPF>();                 // the slot's image is free for the next frame
         }
     }
 }

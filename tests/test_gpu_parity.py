@@ -529,3 +529,41 @@ def test_fft_hops_and_long_runs(sdr, oracle, nfft):
             assert np.abs(lin - want_lin[0]).max() <= 1e-5 * peak, (nfft, hop, f)
             strong = want_lin[0] > peak * 1e-5
             assert np.abs(got[f] - want_db[0])[strong].max() <= 1e-3, (nfft, hop, f)
+
+
+@pytest.mark.gpu
+def test_full_size_stream_properties(sdr, oracle):
+    """BASELINE config 2 size (more than 2^32 bytes of input in one launch): slices at the start,
+    across the 2^31- and 2^32-byte marks and at the ragged end against the oracle, and a time-block
+    launch over the upper part of the same buffer against the one-piece result."""
+    n = (1 << 30) + 12_347
+    T, D = 64, 10
+    h = oracle.create_fir_filter(T, 1.0 / D, "hann")
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM)
+    d_in = sdr.DevBuf(4 * n + 64)
+    sdr.capi.synth_fm_i16_dev(d_in, n, fs=20.0e6, ftone=1000.0, dev=5000.0, noise_lsb=3, seed=11)
+    cnt = plan.out_count(n)
+    assert cnt == n // D - 1
+    d_out = sdr.DevBuf(4 * cnt + 64)
+    assert plan.execute_dev(d_in, n, d_out, cnt) == cnt
+    sdr.sync()
+    m = 4096
+    for j0 in (0, (1 << 29) // D - m // 2, (1 << 30) // D - m // 2, cnt - m):
+        s_lo = max(0, j0 * D - (T - 1))
+        s_hi = min(n, (j0 + m) * D + 1)
+        iq = d_in.to_numpy(np.int16, 2 * (s_hi - s_lo), 4 * s_lo)
+        y = oracle.fir_decimate(oracle.unpack_scale_i16(iq), D, h, pre=j0 * D - s_lo)
+        want = oracle.polar_discriminator(y, 1 / TWO_PI)[:m]
+        got = d_out.to_numpy(np.float32, want.size, 4 * j0)
+        check_fm(got, want, y[: want.size + 1], 1 / TWO_PI, f"slice at output {j0}")
+    # upper part as a time block with its history halo resident
+    ob = (3 << 28) // D + 3
+    lo = ob * D - (T - 1)
+    d_blk = sdr.DevBuf(4 * (cnt - ob) + 64)
+    plan.execute_range_dev(d_in.at(4 * lo), lo, n - lo, n, ob, cnt, d_blk)
+    sdr.sync()
+    for off in (0, (cnt - ob) // 2, cnt - ob - m):
+        a = d_blk.to_numpy(np.float32, m, 4 * off)
+        b = d_out.to_numpy(np.float32, m, 4 * (ob + off))
+        assert np.abs(a.astype(np.float64) - b).max() <= 2e-7       # equal up to the tile-end successor's last bit
+        assert np.count_nonzero(a != b) <= 2 * (m // 512 + 2)

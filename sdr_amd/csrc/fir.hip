@@ -10,9 +10,9 @@
 //
 // Work assignment ("output stride"): a workgroup of NT lanes owns a tile of NT*R consecutive
 // outputs; lane l owns outputs m0 = M0 + l*R .. m0+R-1.  The input window of the tile,
-//   samples W0 = D*M0 - Tback  ..  D*(M0+NT*R) + 1        (Tback = (T-1) rounded up to 4),
-// i.e. the tile's own D*NT*R samples plus the overlap-save halo of T-1 history samples (and D
-// more on the right for the discriminator's successor), is staged once in LDS and every lane
+//   samples W0 = D*M0 - Tback  ..  D*(M0+NT*R)            (Tback = (T-1) rounded up to 4),
+// i.e. the tile's own D*NT*R samples plus the overlap-save halo of T-1 history samples, is
+// staged once in LDS and every lane
 // walks its own window [D*R*l, D*R*l + Lw) with 16-byte LDS reads.  One loaded sample feeds all
 // R outputs of the lane: output r uses tap D*r + Tback - j at window offset j, which the host
 // lays out as a zero-padded table gtab[j][r]; the table index is wave-uniform, so taps arrive
@@ -32,8 +32,8 @@
 // distinct banks.
 //
 // Numerics: float32 fmaf accumulation in ascending window order (identical for every tile
-// placement, except the y a tile's last discriminator output takes from successor_output(): a
-// wave-wide sum, so that one output can differ in the last bit between two tilings); decimation
+// placement: with the discriminator a tile advances by (NT-1)*R outputs and its last lane only
+// computes the successor y of its neighbour, so every output has one summation order); decimation
 // indexing is exact (output m <-> input D*m); zero pre-history (samples < 0 read as 0) as the
 // reference.  For int16 input the exact 2^-11 Q11 scale is folded into the
 // taps.
@@ -69,6 +69,8 @@ struct FirGeom {
     int mode;               // sdr_mode
     int swap_iq;            // 1: the first component of an input pair is Q (SDR_IN_I16_QI)
     float scale;            // discriminator scale
+    int per_tile;           // outputs a tile emits: NT*R, or (NT-1)*R with the discriminator (the
+                            // last lane's y only serves as its neighbour's successor)
     int tiles_per_ch;
     int tiles_per_xcd;      // ceil(tiles_per_ch / 8)
     int total_tiles;
@@ -175,14 +177,15 @@ __device__ __forceinline__ void nt_store(float *p, float a, float b, float c, fl
 template <int R>
 __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict__ outv,
                                               long long ch, long long m0, const float2 (&y)[R],
-                                              float2 ynext)
+                                              float2 ynext, long long tile_end)
 {
+    const long long out_end = tile_end < g.out_end ? tile_end : g.out_end;   // this tile's share ends here
     if (g.mode == SDR_MODE_IQ) {
         float2 *out = (float2 *)outv + ch * g.out_stride;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long long j = m0 + r;
-            if (j >= g.out_begin && j < g.out_end) nt_store((float *)(out + (j - g.out_begin)), y[r].x, y[r].y);
+            if (j >= g.out_begin && j < out_end) nt_store((float *)(out + (j - g.out_begin)), y[r].x, y[r].y);
         }
         return;
     }
@@ -201,7 +204,7 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
     }
     float *out = (float *)outv + ch * g.out_stride;
     float *dst = out + (m0 - g.out_begin);
-    const bool whole = (m0 >= g.out_begin) && (m0 + R <= g.out_end);
+    const bool whole = (m0 >= g.out_begin) && (m0 + R <= out_end);
     if (R >= 2 && whole && (((uintptr_t)dst) & (R >= 4 ? 15 : 7)) == 0) {
         if (R == 2) {
             nt_store(dst, v[0], v[1]);
@@ -214,7 +217,7 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long long j = m0 + r;
-            if (j >= g.out_begin && j < g.out_end) nt_store(dst + r, v[r]);
+            if (j >= g.out_begin && j < out_end) nt_store(dst + r, v[r]);
         }
     }
 }
@@ -331,34 +334,9 @@ __device__ __forceinline__ void walk(const FirGeom &g, const uint4 *lds4,
     else walk_p<SPG, R, false>(g, lds4, gtab, tid, acc);
 }
 
-// Successor of the tile's last output, y[M0 + NT*R], for the discriminator: the T taps are spread
-// over wave 0's lanes and summed across the wave.
-template <int SPG>
-__device__ __forceinline__ float2 successor_output(const FirGeom &g, const unsigned char *tile,
-                                                   const float *taps, int tid, int NT, int R)
-{
-    float2 part = make_float2(0.f, 0.f);
-    const int sbase = g.D * NT * R + g.Tback;          // window offset of sample D*(M0+NT*R)
-    for (int i = tid; i < g.T; i += 64) {
-        const int sidx = sbase - i;
-        const float h = taps[i];
-        float xi, xq;
-        if (SPG == 4) {
-            const uint32_t wv = ((const uint32_t *)tile)[lds_granule(g, sidx >> 2) * 4 + (sidx & 3)];
-            xi = lo16(wv); xq = hi16(wv);
-        } else {
-            const float2 x = ((const float2 *)tile)[lds_granule(g, sidx >> 1) * 2 + (sidx & 1)];
-            xi = x.x; xq = x.y;
-        }
-        part.x = __fmaf_rn(h, xi, part.x);
-        part.y = __fmaf_rn(h, xq, part.y);
-    }
-    return wave_sum(part);
-}
-
 // ---------------------------------------------------------------------------------------------
 // fir_stream_kernel: float2 tiles, convert once, persistent workgroups with register prefetch.
-// LDS: [tile (a_gran float4) | ybuf (NT+2 float2) | taps (T float)].
+// LDS: [tile (a_gran float4) | ybuf (NT+2 float2)].
 // ---------------------------------------------------------------------------------------------
 template <int IN> struct RawPair;                        // two consecutive input samples
 template <> struct RawPair<IN_I16> { typedef uint2 type; };
@@ -461,7 +439,7 @@ constexpr int kSlotsSmall = 12, kSlots = 32;   // 2-sample granules one lane sta
 template <int IN, int R, int SLOTS>
 __global__ void __launch_bounds__(256, (SLOTS <= kSlotsSmall ? 3 : 2))
 fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
-                  const float *__restrict__ gtab, const float *__restrict__ taps, const FirGeom g)
+                  const float *__restrict__ gtab, const FirGeom g)
 {
     typedef typename RawPair<IN>::type P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -469,8 +447,6 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
     const int NT = blockDim.x;
     float4 *tile = (float4 *)smem;
     float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 16);
-    float *ltaps = (float *)(smem + (size_t)g.a_gran * 16 + (size_t)(NT + 2) * 8);
-    for (int i = tid; i < g.T; i += NT) ltaps[i] = taps[i];
 
     // Per-slot constants (the same for every tile): the sample granule this lane stages in slot k
     // and its byte offset from the tile window's first sample.  Slots past the tile are clamped
@@ -496,9 +472,9 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
     };
 
     int t = blockIdx.x;
-    if (t < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, t, NT * R));
+    if (t < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, t, g.per_tile));
     for (; t < g.total_tiles; t += gridDim.x) {
-        const TileRef tr = tile_ref<IN>(g, in, t, NT * R);
+        const TileRef tr = tile_ref<IN>(g, in, t, g.per_tile);
         __syncthreads();                         // every lane has finished with the previous tile
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
@@ -510,7 +486,7 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
         // request the next tile now: its HBM latency is covered by the walk below
         {
             const int tn = t + gridDim.x;
-            if (tn < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, tn, NT * R));
+            if (tn < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, tn, g.per_tile));
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -521,14 +497,10 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
         float2 ynext = make_float2(0.f, 0.f);
         if (g.mode == SDR_MODE_FM) {
             ybuf[tid] = acc[0];
-            if (tid < 64) {
-                const float2 ys = successor_output<2>(g, smem, ltaps, tid, NT, R);
-                if (tid == 0) ybuf[NT] = ys;
-            }
             __syncthreads();
-            ynext = ybuf[tid + 1];
+            ynext = ybuf[tid + 1];                 // the last lane's is unused: it emits nothing
         }
-        store_outputs<R>(g, outv, tr.ch, m0, acc, ynext);
+        store_outputs<R>(g, outv, tr.ch, m0, acc, ynext, tr.M0 + g.per_tile);
     }
 }
 
@@ -557,7 +529,7 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 template <int R>
 __global__ void __launch_bounds__(256)
 fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
-               const float *__restrict__ gtab, const float *__restrict__ taps, const FirGeom g)
+               const float *__restrict__ gtab, const FirGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *lds4 = (uint4 *)smem;
@@ -566,7 +538,7 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     const long long ch = blockIdx.y;
     const int tile = xcd_tile(g);
     if (tile >= g.tiles_per_ch) return;
-    const long long M0 = g.tile0 + (long long)tile * (NT * R);
+    const long long M0 = g.tile0 + (long long)tile * g.per_tile;
     const long long W0 = M0 * g.D - g.Tback;                 // first staged sample (multiple of 4)
     const uint32_t *src = in + ch * g.in_stride;             // sample 0 of this channel
 
@@ -608,15 +580,10 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     if (g.mode == SDR_MODE_FM) {
         float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 16);
         ybuf[tid] = acc[0];
-        if (tid < 64) {
-            float2 ys = successor_output<4>(g, smem, taps, tid, NT, R);
-            if (g.swap_iq) ys = make_float2(ys.y, ys.x);
-            if (tid == 0) ybuf[NT] = ys;
-        }
         __syncthreads();
-        ynext = ybuf[tid + 1];
+        ynext = ybuf[tid + 1];                 // the last lane's is unused: it emits nothing
     }
-    store_outputs<R>(g, outv, ch, m0, acc, ynext);
+    store_outputs<R>(g, outv, ch, m0, acc, ynext, M0 + g.per_tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -709,21 +676,6 @@ __device__ __forceinline__ void pwalk_p(const FirGeom &g, const float4 *re4, con
     for (int r = 0; r < R; ++r) acc[r] = make_float2(ar[r], ai[r]);
 }
 
-__device__ __forceinline__ float2 successor_planar(const FirGeom &g, const float *re, const float *im,
-                                                   const float *taps, int tid, int NT, int R)
-{
-    float2 part = make_float2(0.f, 0.f);
-    const int sbase = g.D * NT * R + g.Tback;          // window offset of sample D*(M0+NT*R)
-    for (int i = tid; i < g.T; i += 64) {
-        const int sidx = sbase - i;
-        const int at = lds_granule(g, sidx >> 2) * 4 + (sidx & 3);
-        const float h = taps[i];
-        part.x = __fmaf_rn(h, re[at], part.x);
-        part.y = __fmaf_rn(h, im[at], part.y);
-    }
-    return wave_sum(part);
-}
-
 constexpr int kPlanarSlots = 8;     // granules one lane stages per round of loads
 
 // Stage one tile as two float planes: every lane fetches its granules (4 int16 pairs each), converts
@@ -768,7 +720,7 @@ __device__ __forceinline__ void stage_planar(const FirGeom &g, const uint32_t *_
 template <int R>
 __global__ void __launch_bounds__(256)
 fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
-                  const float *__restrict__ gtab, const float *__restrict__ taps, const FirGeom g)
+                  const float *__restrict__ gtab, const FirGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *re4 = (float4 *)smem;
@@ -778,7 +730,7 @@ fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     const long long ch = blockIdx.y;
     const int tile = xcd_tile(g);
     if (tile >= g.tiles_per_ch) return;
-    const long long M0 = g.tile0 + (long long)tile * (NT * R);
+    const long long M0 = g.tile0 + (long long)tile * g.per_tile;
     const long long W0 = M0 * g.D - g.Tback;                 // first staged sample (multiple of 4)
     const uint32_t *src = in + ch * g.in_stride;             // sample 0 of this channel
 
@@ -795,14 +747,10 @@ fir_planar_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     if (g.mode == SDR_MODE_FM) {
         float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 32);
         ybuf[tid] = acc[0];
-        if (tid < 64) {
-            const float2 ys = successor_planar(g, (const float *)re4, (const float *)im4, taps, tid, NT, R);
-            if (tid == 0) ybuf[NT] = ys;
-        }
         __syncthreads();
-        ynext = ybuf[tid + 1];
+        ynext = ybuf[tid + 1];                 // the last lane's is unused: it emits nothing
     }
-    store_outputs<R>(g, outv, ch, m0, acc, ynext);
+    store_outputs<R>(g, outv, ch, m0, acc, ynext, M0 + g.per_tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -823,7 +771,7 @@ constexpr int kMfmaAhead = 4;      // operand prefetch distance, in k-chunks of 
 
 __global__ void __launch_bounds__(256)
 fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
-                const float4 *__restrict__ atab, const float *__restrict__ taps, const FirGeom g)
+                const float4 *__restrict__ atab, const FirGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *re4 = (float4 *)smem;
@@ -834,7 +782,7 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     const long long ch = blockIdx.y;
     const int tile = xcd_tile(g);
     if (tile >= g.tiles_per_ch) return;
-    const long long M0 = g.tile0 + (long long)tile * (NT * R);
+    const long long M0 = g.tile0 + (long long)tile * g.per_tile;
     const long long W0 = M0 * g.D - g.Tback;
     const uint32_t *src = in + ch * g.in_stride;
     stage_planar(g, src, W0, re4, im4, tid, NT);
@@ -882,14 +830,10 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         yb[4] = acc0[2] + acc1[2];
         yb[6] = acc0[3] + acc1[3];
     }
-    if (g.mode == SDR_MODE_FM && tid < 64) {
-        const float2 ys = successor_planar(g, (const float *)re4, (const float *)im4, taps, tid, NT, R);
-        if (tid == 0) ybuf[NT * R] = ys;
-    }
     __syncthreads();
     const float2 y[R] = {ybuf[2 * tid], ybuf[2 * tid + 1]};
-    const float2 ynext = ybuf[2 * tid + 2];                // FM only; slot 512 is the successor
-    store_outputs<R>(g, outv, ch, M0 + 2LL * tid, y, ynext);
+    const float2 ynext = ybuf[2 * tid + 2];                // FM only; the last lane's is unused
+    store_outputs<R>(g, outv, ch, M0 + 2LL * tid, y, ynext, M0 + g.per_tile);
 }
 
 }  // namespace
@@ -907,7 +851,7 @@ struct sdr_fir_plan {
     int spg;                // samples per LDS granule: 4 (raw) / 2 (stream)
     int Tback, Lw4, ngran, q, pad, s_gran, a_gran, n_inst, lds_bytes;
     int stream_blocks = 0;  // persistent grid: CUs x resident workgroups per CU
-    float *d_gtab = nullptr, *d_taps = nullptr;
+    float *d_gtab = nullptr;
     // staging buffers for the *_host entry point
     void *d_in = nullptr, *d_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
@@ -934,8 +878,7 @@ bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *
     o->q = D * R / spg;
     o->pad = (o->q % 2 == 0) ? 1 : 0;
     const long long s_need = (long long)D * R * (NT - 1) + (long long)(o->ngran + o->look) * spg;
-    const long long s_fm = (long long)D * R * NT + o->Tback + 1;
-    const long long s_tile = s_need > s_fm ? s_need : s_fm;
+    const long long s_tile = s_need;
     if (s_tile > (1LL << 22)) return false;
     o->s_gran = (int)((s_tile + spg - 1) / spg);
     const int a = o->s_gran + (o->pad ? o->s_gran / o->q + 1 : 0);
@@ -944,7 +887,7 @@ bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *
     // per CU fits in the 160 KB)
     o->a_gran = stream ? roundup(a, NT) : a;
     o->n_inst = (o->a_gran + NT - 1) / NT;
-    o->lds_bytes = o->a_gran * (planar ? 32 : 16) + (NT + 2) * 8 + (stream ? roundup(T, 4) * 4 : 0);
+    o->lds_bytes = o->a_gran * (planar ? 32 : 16) + (NT + 2) * 8;
     return true;
 }
 
@@ -960,7 +903,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
             (void)hipFuncSetAttribute((const void *)fir_mfma_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
         fir_mfma_kernel<<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), 256, p->lds_bytes, st>>>(
-            (const uint32_t *)in, out, p->d_atab, p->d_taps, g);
+            (const uint32_t *)in, out, p->d_atab, g);
         return hipGetLastError();
     }
     if (p->planar) {
@@ -968,7 +911,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
             (void)hipFuncSetAttribute((const void *)fir_planar_kernel<R>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
         fir_planar_kernel<R><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
-                                                                           p->d_gtab, p->d_taps, g);
+                                                                           p->d_gtab, g);
         return hipGetLastError();
     }
     if (p->raw) {
@@ -976,7 +919,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
             (void)hipFuncSetAttribute((const void *)fir_raw_kernel<R>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
         fir_raw_kernel<R><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
-                                                                        p->d_gtab, p->d_taps, g);
+                                                                        p->d_gtab, g);
         return hipGetLastError();
     }
     const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
@@ -985,7 +928,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         if (p->lds_bytes > 64 * 1024)                                                            \
             (void)hipFuncSetAttribute((const void *)fir_stream_kernel<INK, R, SL>,               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes); \
-        fir_stream_kernel<INK, R, SL><<<nb, p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, p->d_taps, g); \
+        fir_stream_kernel<INK, R, SL><<<nb, p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, g); \
     } while (0)
     const bool small = p->n_inst <= kSlotsSmall;
     if (p->input == SDR_IN_I16_IQ || p->input == SDR_IN_I16_QI) { if (small) SDR_STREAM(IN_I16, kSlotsSmall); else SDR_STREAM(IN_I16, kSlots); }
@@ -1021,7 +964,9 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.s_gran = p->s_gran; g.a_gran = p->a_gran; g.n_inst = p->n_inst; g.mode = p->mode;
     g.swap_iq = (p->input == SDR_IN_I16_QI) ? 1 : 0;
     g.scale = (float)p->scale;
-    const long long per_tile = (long long)p->NT * p->R;
+    // with the discriminator a tile's last lane only supplies its neighbour's successor y
+    const long long per_tile = (long long)(p->mode == SDR_MODE_FM ? p->NT - 1 : p->NT) * p->R;
+    g.per_tile = (int)per_tile;
     const long long tiles = (out_end - g.tile0 + per_tile - 1) / per_tile;
     if (tiles * (long long)n_ch > 0x7fffffffLL) { sdr::set_error("too many tiles"); return SDR_EINVAL; }
     g.tiles_per_ch = (int)tiles;
@@ -1100,8 +1045,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const int nq = roundup(W / 16, kMfmaAhead);
         gm.ngran = nq;                                      // k-chunks of 16
         const long long s_a = (long long)p->D * 16 * 31 + 16LL * (nq + kMfmaAhead);   // last group + look-ahead chunks
-        const long long s_b = (long long)gm.Tback + (long long)p->D * 512 + 1;  // the discriminator's successor
-        const long long s_tile = s_a > s_b ? s_a : s_b;
+        const long long s_tile = s_a;
         gm.s_gran = (int)((s_tile + 3) / 4);
         gm.a_gran = gm.s_gran;
         gm.n_inst = (gm.a_gran + 255) / 256;
@@ -1213,9 +1157,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
     if (e == hipSuccess && p->mfma) e = hipMalloc((void **)&p->d_atab, at.size() * sizeof(float4));
     if (e == hipSuccess && p->mfma) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float4), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_taps, hf.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_gtab, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(p->d_taps, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         sdr_fir_plan_destroy(p);
         return sdr::hip_fail(e, "plan upload");
@@ -1229,7 +1171,6 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (!p) return SDR_OK;
     if (p->d_gtab) (void)hipFree(p->d_gtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
-    if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     delete p;

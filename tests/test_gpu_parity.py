@@ -565,5 +565,4 @@ def test_full_size_stream_properties(sdr, oracle):
     for off in (0, (cnt - ob) // 2, cnt - ob - m):
         a = d_blk.to_numpy(np.float32, m, 4 * off)
         b = d_out.to_numpy(np.float32, m, 4 * (ob + off))
-        assert np.abs(a.astype(np.float64) - b).max() <= 2e-7       # equal up to the tile-end successor's last bit
-        assert np.count_nonzero(a != b) <= 2 * (m // 512 + 2)
+        assert np.array_equal(a, b)          # one summation order per output, whatever the tiling

@@ -566,3 +566,39 @@ def test_full_size_stream_properties(sdr, oracle):
         a = d_blk.to_numpy(np.float32, m, 4 * off)
         b = d_out.to_numpy(np.float32, m, 4 * (ob + off))
         assert np.array_equal(a, b)          # one summation order per output, whatever the tiling
+
+
+@pytest.mark.gpu
+def test_time_shard_beyond_2_pow_32_samples(sdr, oracle):
+    """the last of eight 2^30-sample time shards: stream indices above 2^32 samples (2^34 bytes)
+    reach the kernel only through the 64-bit range arguments and the virtual base pointer"""
+    from sdr_amd import shard
+    T, D = 64, 10
+    n_total = 8 << 30
+    h = oracle.create_fir_filter(T, 1.0 / D, "hann")
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM)
+    sh = shard.plan_time_shards(n_total, D, T, shard.MODE_FM, 8)[7]
+    assert sh.out_end == plan.out_count(n_total) and sh.lo > (1 << 32)
+    # keep only the last 2^27 outputs of the shard resident (the arithmetic is the same)
+    ob = sh.out_end - (1 << 27)
+    lo = ob * D - (T - 1)
+    n_res = sh.hi - lo
+    d_in = sdr.DevBuf(4 * n_res + 64)
+    sdr.capi.synth_fm_i16_dev(d_in, n_res, n0=lo, fs=20.0e6, ftone=1000.0, dev=5000.0, noise_lsb=2, seed=4)
+    d_out = sdr.DevBuf(4 * (sh.out_end - ob) + 64)
+    plan.execute_range_dev(d_in, lo, n_res, n_total, ob, sh.out_end, d_out)
+    sdr.sync()
+    m = 4096
+    for j0 in (0, (sh.out_end - ob) // 2 + 77, sh.out_end - ob - m):
+        J = ob + j0
+        s_lo = J * D - (T - 1)
+        s_hi = min(sh.hi, (J + m) * D + 1)
+        iq = d_in.to_numpy(np.int16, 2 * (s_hi - s_lo), 4 * (s_lo - lo))
+        y = oracle.fir_decimate(oracle.unpack_scale_i16(iq), D, h, pre=T - 1)
+        want = oracle.polar_discriminator(y, 1 / TWO_PI)[:m]
+        got = d_out.to_numpy(np.float32, want.size, 4 * j0)
+        check_fm(got, want, y[: want.size + 1], 1 / TWO_PI, f"shard output {J}")
+    # asking for outputs whose samples are not resident is refused
+    with pytest.raises(sdr.SdrError) as e:
+        plan.execute_range_dev(d_in, lo, n_res, n_total, ob - 10, sh.out_end, d_out)
+    assert e.value.status == sdr.capi.ERANGE

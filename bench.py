@@ -200,16 +200,20 @@ def main():
         parity = worst
         assert worst <= 1e-5 * 0.5, f"full-size parity failed: {worst}"
 
-    gather_ms = None
+    gather_ms = gather_error = None
     if dist and not a.no_gather:
         # final collection of the decimated output on rank 0 over xGMI (RCCL gather), once per job
         counts = [sh.n_out for sh in shards]
         torch.cuda.synchronize(); dist.barrier()
         g0 = time.perf_counter()
-        gathered = shard.gather_outputs(d_out.cpu() if a.rehearse else d_out, counts, dist, dst=0)
-        torch.cuda.synchronize(); dist.barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        if rank == 0:
+        try:
+            gathered = shard.gather_outputs(d_out.cpu() if a.rehearse else d_out, counts, dist, dst=0)
+            torch.cuda.synchronize(); dist.barrier()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+        except Exception as e:                    # the timed result above stands; report, do not lose the line
+            gathered, gather_error = None, f"{type(e).__name__}: {e}"
+            print(f"rank {rank}: final gather failed: {gather_error}", file=sys.stderr)
+        if rank == 0 and gathered is not None:
             assert gathered.numel() == cnt_total
             if a.rehearse:
                 # the gathered shards must equal the whole stream filtered in one piece, bit for bit
@@ -262,6 +266,8 @@ def main():
         }
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)
+        if gather_error is not None:
+            line["gather_error"] = gather_error
         if world == 1 and a.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(O, taps, D, a.cpu_seconds)
             line["cpu_baseline_all_cores"] = cpu_all_cores(O, taps, D, a.cpu_seconds / 3.0)

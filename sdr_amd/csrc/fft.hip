@@ -11,7 +11,7 @@
 //   pass 1 reads the int16 IQ samples straight from HBM (coalesced 4-byte loads at stride N/16),
 //          multiplies by the window table (which also carries the exact 2^-11 * 1/N scale),
 //   the last pass computes |X|^2 -> 10*log10 and stores the fft-shifted row, coalesced.
-// A 256-lane workgroup holds 4096/N frames; the LDS exchange image is padded by one float2 per
+// A 256-lane workgroup holds 4096/N frames; the LDS exchange image is padded by one complex value per
 // 16 so that the stride-16 scatter of pass 1 and the stride-N/16 gathers hit distinct banks.
 // Twiddles come from a table exp(-2*pi*i*k/N) in global memory (L1/L2 resident).
 
@@ -22,20 +22,59 @@
 
 namespace {
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
-{
-    return make_float2(__fmaf_rn(a.x, b.x, -(a.y * b.y)), __fmaf_rn(a.x, b.y, a.y * b.x));
-}
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// a - j*b  and  a + j*b
-__device__ __forceinline__ float2 csub_j(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }
-__device__ __forceinline__ float2 cadd_j(float2 a, float2 b) { return make_float2(a.x - b.y, a.y + b.x); }
+// Complex values are register pairs and every complex operation is packed float32 arithmetic
+// (VOP3P: one 4-cycle wave64 instruction computes both halves; a plain v_add_f32 takes the same 4
+// cycles for one): a +- b is one v_pk_add_f32, a -+ j*b one v_pk_add_f32 whose op_sel swaps the
+// halves of b, a complex product one v_pk_mul_f32 + one v_pk_fma_f32.  The half selection and
+// sign modifiers have no C++ spelling, hence the asm.
+typedef float cf __attribute__((ext_vector_type(2)));
 
-// forward 4-point DFT (kernel e^{-j 2 pi nk/4}), natural order in and out
-__device__ __forceinline__ void dft4(float2 &x0, float2 &x1, float2 &x2, float2 &x3)
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b)
 {
-    const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = csub(x1, x3);
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - j*b = (a.x + b.y, a.y - b.x)  and  a + j*b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf csub_j(cf a, cf b)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf cadd_j(cf a, cf b)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// r = a * (p + j*q) with p = (PN ? - : +) W[PI], q = (QN ? - : +) W[QI] taken from the halves of the
+// register pair W (NQN = !QN):  t = (a.x*p, a.x*q);  r = (t.x - a.y*q, t.y + a.y*p)
+#define SDR_CMUL(r, a, W, PI, PN, QI, QN, NQN)                                                     \
+    do {                                                                                           \
+        cf t_;                                                                                     \
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0," #PI "] op_sel_hi:[0," #QI "] neg_lo:[0," #PN      \
+            "] neg_hi:[0," #QN "]" : "=v"(t_) : "v"(a), "v"(W));                                   \
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1," #QI ",0] op_sel_hi:[1," #PI ",1] neg_lo:[0,"  \
+            #NQN ",0] neg_hi:[0," #PN ",0]" : "=v"(r) : "v"(a), "v"(W), "v"(t_));                  \
+    } while (0)
+
+__device__ __forceinline__ cf cmul(cf a, cf w)
+{
+    cf r;
+    SDR_CMUL(r, a, w, 0, 0, 1, 0, 1);
+    return r;
+}
+
+// forward 4-point DFT (kernel e^{-j 2 pi nk/4}), natural order in and out.  ROT2: x2 stands for
+// -j*x2 (the rotation folds into the first butterfly instead of costing an instruction).
+template <bool ROT2 = false>
+__device__ __forceinline__ void dft4(cf &x0, cf &x1, cf &x2, cf &x3)
+{
+    const cf t0 = ROT2 ? csub_j(x0, x2) : cadd(x0, x2), t1 = ROT2 ? cadd_j(x0, x2) : csub(x0, x2);
+    const cf t2 = cadd(x1, x3), t3 = csub(x1, x3);
     x0 = cadd(t0, t2);
     x2 = csub(t0, t2);
     x1 = csub_j(t1, t3);
@@ -43,59 +82,60 @@ __device__ __forceinline__ void dft4(float2 &x0, float2 &x1, float2 &x2, float2 
 }
 
 template <int R>
-__device__ __forceinline__ void dft(float2 (&x)[R]);
+__device__ __forceinline__ void dft(cf (&x)[R]);
 
 template <>
-__device__ __forceinline__ void dft<2>(float2 (&x)[2])
+__device__ __forceinline__ void dft<2>(cf (&x)[2])
 {
-    const float2 a = x[0], b = x[1];
+    const cf a = x[0], b = x[1];
     x[0] = cadd(a, b);
     x[1] = csub(a, b);
 }
 
 template <>
-__device__ __forceinline__ void dft<4>(float2 (&x)[4]) { dft4(x[0], x[1], x[2], x[3]); }
+__device__ __forceinline__ void dft<4>(cf (&x)[4]) { dft4(x[0], x[1], x[2], x[3]); }
 
 // 8 = 2 x 4:  n = a + 2m, k = b + 4c:  X[b + 4c] = sum_a W8^{ab} (-1)^{ac} DFT4_m(x[a+2m])[b]
 template <>
-__device__ __forceinline__ void dft<8>(float2 (&x)[8])
+__device__ __forceinline__ void dft<8>(cf (&x)[8])
 {
-    const float s = 0.70710678118654752f;
-    float2 u0[4] = {x[0], x[2], x[4], x[6]};
-    float2 u1[4] = {x[1], x[3], x[5], x[7]};
+    const cf W2 = {0.70710678118654752f, 0.70710678118654752f};
+    cf u0[4] = {x[0], x[2], x[4], x[6]};
+    cf u1[4] = {x[1], x[3], x[5], x[7]};
     dft4(u0[0], u0[1], u0[2], u0[3]);
     dft4(u1[0], u1[1], u1[2], u1[3]);
-    u1[1] = cmul(u1[1], make_float2(s, -s));
-    u1[2] = make_float2(u1[2].y, -u1[2].x);                 // * (-j)
-    u1[3] = cmul(u1[3], make_float2(-s, -s));
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        x[b] = cadd(u0[b], u1[b]);
-        x[b + 4] = csub(u0[b], u1[b]);
-    }
+    SDR_CMUL(u1[1], u1[1], W2, 0, 0, 1, 1, 0);              // * (s - j s)
+    SDR_CMUL(u1[3], u1[3], W2, 0, 1, 1, 1, 0);              // * (-s - j s)
+    x[0] = cadd(u0[0], u1[0]);  x[4] = csub(u0[0], u1[0]);
+    x[1] = cadd(u0[1], u1[1]);  x[5] = csub(u0[1], u1[1]);
+    x[2] = csub_j(u0[2], u1[2]);  x[6] = cadd_j(u0[2], u1[2]);   // u1[2] * (-j)
+    x[3] = cadd(u0[3], u1[3]);  x[7] = csub(u0[3], u1[3]);
 }
 
 // 16 = 4 x 4:  n = a + 4m, k = b + 4c:  X[b + 4c] = DFT4_a( W16^{ab} * DFT4_m(x[a+4m])[b] )[c]
 template <>
-__device__ __forceinline__ void dft<16>(float2 (&x)[16])
+__device__ __forceinline__ void dft<16>(cf (&x)[16])
 {
-    const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, c2 = 0.70710678118654752f;
+    const cf W1 = {0.92387953251128674f, 0.38268343236508977f};     // (c1, s1)
+    const cf W2 = {0.70710678118654752f, 0.70710678118654752f};     // (c2, c2)
 #pragma unroll
     for (int a = 0; a < 4; ++a) dft4(x[a], x[a + 4], x[a + 8], x[a + 12]);
     // after this, x[a + 4b] = u[a][b]; twiddle W16^{ab} = exp(-j*2*pi*a*b/16)
-    x[1 + 4] = cmul(x[1 + 4], make_float2(c1, -s1));        // ab = 1
-    x[2 + 4] = cmul(x[2 + 4], make_float2(c2, -c2));        // 2
-    x[3 + 4] = cmul(x[3 + 4], make_float2(s1, -c1));        // 3
-    x[1 + 8] = cmul(x[1 + 8], make_float2(c2, -c2));        // 2
-    x[2 + 8] = make_float2(x[2 + 8].y, -x[2 + 8].x);        // 4: -j
-    x[3 + 8] = cmul(x[3 + 8], make_float2(-c2, -c2));       // 6
-    x[1 + 12] = cmul(x[1 + 12], make_float2(s1, -c1));      // 3
-    x[2 + 12] = cmul(x[2 + 12], make_float2(-c2, -c2));     // 6
-    x[3 + 12] = cmul(x[3 + 12], make_float2(-c1, s1));      // 9
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(x[4 * b], x[4 * b + 1], x[4 * b + 2], x[4 * b + 3]);
+    SDR_CMUL(x[1 + 4], x[1 + 4], W1, 0, 0, 1, 1, 0);        // ab = 1:  c1 - j s1
+    SDR_CMUL(x[2 + 4], x[2 + 4], W2, 0, 0, 1, 1, 0);        // 2:  c2 - j c2
+    SDR_CMUL(x[3 + 4], x[3 + 4], W1, 1, 0, 0, 1, 0);        // 3:  s1 - j c1
+    SDR_CMUL(x[1 + 8], x[1 + 8], W2, 0, 0, 1, 1, 0);        // 2
+    /* x[2 + 8] * (-j), ab = 4: folded into the b = 2 butterfly below */
+    SDR_CMUL(x[3 + 8], x[3 + 8], W2, 0, 1, 1, 1, 0);        // 6: -c2 - j c2
+    SDR_CMUL(x[1 + 12], x[1 + 12], W1, 1, 0, 0, 1, 0);      // 3
+    SDR_CMUL(x[2 + 12], x[2 + 12], W2, 0, 1, 1, 1, 0);      // 6
+    SDR_CMUL(x[3 + 12], x[3 + 12], W1, 0, 1, 1, 0, 1);      // 9: -c1 + j s1
+    dft4(x[0], x[1], x[2], x[3]);
+    dft4(x[4], x[5], x[6], x[7]);
+    dft4<true>(x[8], x[9], x[10], x[11]);
+    dft4(x[12], x[13], x[14], x[15]);
     // now x[4b + c] = X[b + 4c]: transpose to natural order
-    float2 y[16];
+    cf y[16];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -105,6 +145,15 @@ __device__ __forceinline__ void dft<16>(float2 (&x)[16])
 }
 
 __device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
+
+// Measurement builds only (tools/fft_ablate.sh; the results are wrong by construction):
+// bit 0 = no LDS exchanges (later passes take the lane's own registers), bit 1 = no butterflies,
+// bit 2 = no log, bit 3 = every workgroup stores to one row of its own (the stores stay in L2), bit 4 = the
+// sample loads read one cached row.  The shipped library is built with 0.
+#ifndef SDR_FFT_ABLATE
+#define SDR_FFT_ABLATE 0
+#endif
+
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
 // would wait for the next frame's prefetched samples and the previous frame's dB stores at every
@@ -135,8 +184,8 @@ struct FftGeom {
 // twiddles of one Stockham pass for butterfly index j: W_{Ns*R}^{t*k}, k = j mod Ns, t = 1..R-1.
 // They depend on the lane only, so a persistent lane loads them once.
 template <int N, int R>
-__device__ __forceinline__ void pass_twiddles(float2 (&w)[R > 1 ? R - 1 : 1], int j, int Ns,
-                                              const float2 *__restrict__ tw)
+__device__ __forceinline__ void pass_twiddles(cf (&w)[R > 1 ? R - 1 : 1], int j, int Ns,
+                                              const cf *__restrict__ tw)
 {
     const int k = j & (Ns - 1);
     const int step = N / (Ns * R);
@@ -147,23 +196,29 @@ __device__ __forceinline__ void pass_twiddles(float2 (&w)[R > 1 ? R - 1 : 1], in
 // One Stockham pass on registers: inputs gathered from `lds` at j + t*N/R, twiddled, R-point DFT.
 // Natural-order bin of output t is (j/Ns)*Ns*R + (j mod Ns) + t*Ns.
 template <int N, int R>
-__device__ __forceinline__ void pass_load(float2 (&x)[R], const float2 *lds, int j,
-                                          const float2 (&w)[R > 1 ? R - 1 : 1])
+__device__ __forceinline__ void pass_load(cf (&x)[R], const cf *lds, int j,
+                                          const cf (&w)[R > 1 ? R - 1 : 1])
 {
+    if constexpr (!(SDR_FFT_ABLATE & 1)) {
 #pragma unroll
-    for (int t = 0; t < R; ++t) x[t] = lds[pidx(j + t * (N / R))];
+        for (int t = 0; t < R; ++t) x[t] = lds[pidx(j + t * (N / R))];
+    }
 #pragma unroll
     for (int t = 1; t < R; ++t) x[t] = cmul(x[t], w[t - 1]);
-    dft<R>(x);
+    if constexpr (!(SDR_FFT_ABLATE & 2)) dft<R>(x);
 }
 
 // 20*log10|X| = 10*log10(|X|^2) through the hardware log2 (v_log_f32, ~1 ulp): exact zero power
-// gives -inf like the reference's log10(0).
+// gives -inf like the reference's log10(0).  Two bins at a time so that the squares and the final
+// scale are packed operations too.
 template <int N>
-__device__ __forceinline__ void emit_db(float *__restrict__ row, int bin, float2 v)
+__device__ __forceinline__ void emit_db2(float *__restrict__ row, int bin0, int bin1, cf v0, cf v1)
 {
-    const float p = __fmaf_rn(v.x, v.x, v.y * v.y);
-    row[(bin + N / 2) & (N - 1)] = 3.01029995663981195f * __log2f(p);
+    const cf s0 = v0 * v0, s1 = v1 * v1;
+    cf p = {s0.x + s0.y, s1.x + s1.y};
+    if constexpr (!(SDR_FFT_ABLATE & 4)) p = cf{__log2f(p.x), __log2f(p.y)} * 3.01029995663981195f;
+    row[(bin0 + N / 2) & (N - 1)] = p.x;
+    row[(bin1 + N / 2) & (N - 1)] = p.y;
 }
 
 // N = 16 * R2 * R3 (R3 == 1: two passes).  HALF: hop == N/2, so the second half of a frame is the
@@ -180,24 +235,28 @@ template <int N, int R2, int R3, bool HALF>
 #endif
 __global__ void __launch_bounds__(256, SDR_FFT_MINB)
 fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
-              const float2 *__restrict__ tw, float *__restrict__ out, const FftGeom g)
+              const cf *__restrict__ tw, float *__restrict__ out, const FftGeom g)
 {
     constexpr int TPF = N / 16;            // lanes per frame
     constexpr int FPB = 256 / TPF;         // frame slots per workgroup
-    constexpr int FR_LDS = N + N / 16;     // padded float2 per frame
+    constexpr int FR_LDS = N + N / 16;     // padded complex values per frame
     constexpr int NEW = HALF ? 8 : 16;     // samples a lane fetches per frame
     constexpr int B2 = 16 / R2;            // pass-2 butterflies per lane
     constexpr int Ns3 = 16 * R2;
     constexpr int B3 = R3 > 1 ? 16 / R3 : 1;
     constexpr int NT2 = 16 * (R2 - 1);     // pass-2 twiddle table: W_{16*R2}^{t*k}, k = 0..15, t = 1..R2-1
-    __shared__ float2 smem[FPB * FR_LDS];
-    __shared__ float2 tw2[NT2];
+    __shared__ cf smem[FPB * FR_LDS];
+    __shared__ cf tw2[NT2];
     __shared__ float lwin[N];              // window table (registers are the scarcer resource here)
+#ifdef SDR_FFT_PADLDS                      // measurement builds: fewer resident workgroups per CU
+    __shared__ float padlds[SDR_FFT_PADLDS / 4];
+    if (g.hop < 0) padlds[threadIdx.x] = 1.f, out[0] = padlds[threadIdx.x ^ 1];
+#endif
 
     const int tid = threadIdx.x;
     const int fl = tid / TPF;              // frame slot in the workgroup
     const int tl = tid - fl * TPF;         // lane within the frame
-    float2 *lds = smem + fl * FR_LDS;
+    cf *lds = smem + fl * FR_LDS;
 
     const long long f0 = ((long long)blockIdx.x * FPB + fl) * g.chunk;     // first frame of this slot
     long long f_end = f0 + g.chunk;
@@ -210,7 +269,7 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
         const int k = i / (R2 - 1), t = i - k * (R2 - 1) + 1;
         tw2[i] = tw[t * k * (N / (16 * R2))];
     }
-    float2 w3[B3][R3 > 1 ? R3 - 1 : 1];
+    cf w3[B3][R3 > 1 ? R3 - 1 : 1];
     if constexpr (R3 > 1) {
 #pragma unroll
         for (int i = 0; i < B3; ++i) pass_twiddles<N, R3>(w3[i], tl + i * TPF, Ns3, tw);
@@ -243,7 +302,7 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
         const long long f = f0 + it;
         const bool live = f < f_end;
         // ---- pass 1: radix 16 on the raw samples, Ns = 1 ---------------------------------------
-        float2 x[16];
+        cf x[16];
         uint32_t raw[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) raw[t] = (t < 16 - NEW) ? keep[t % 8] : nxt[t - (16 - NEW)];
@@ -252,29 +311,39 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
             for (int t = 0; t < 8; ++t) keep[t] = nxt[t];
         }
         {                                  // request the next frame's samples now
-            const uint32_t *src = iq + (f + 1 < last ? f + 1 : last) * g.hop;
+            const uint32_t *src = iq + ((SDR_FFT_ABLATE & 16) ? (f & 1) : (f + 1 < last ? f + 1 : last)) * g.hop;
 #pragma unroll
             for (int t = 0; t < NEW; ++t) nxt[t] = src[tl + (t + 16 - NEW) * TPF];
         }
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float wv = lwin[tl + t * TPF];
-            x[t] = make_float2((float)(short)(raw[t] & 0xffffu) * wv, (float)((int)raw[t] >> 16) * wv);
+        for (int t = 0; t < 16; t += 2) {
+            // two window values per register pair; each scales one sample's (I, Q) pair
+            const cf wv = {lwin[tl + t * TPF], lwin[tl + (t + 1) * TPF]};
+            const cf a = {(float)(short)(raw[t] & 0xffffu), (float)((int)raw[t] >> 16)};
+            const cf b = {(float)(short)(raw[t + 1] & 0xffffu), (float)((int)raw[t + 1] >> 16)};
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(x[t]) : "v"(a), "v"(wv));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(x[t + 1]) : "v"(b), "v"(wv));
         }
-        dft<16>(x);
+        if constexpr (!(SDR_FFT_ABLATE & 2)) dft<16>(x);
+        if constexpr (!(SDR_FFT_ABLATE & 1)) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) lds[pidx(tl * 16 + t)] = x[t];
-        frame_sync<TPF>();  
+            for (int t = 0; t < 16; ++t) lds[pidx(tl * 16 + t)] = x[t];
+            frame_sync<TPF>();
+        }
 
-        float *row = live ? out + f * N : g.dummy;
+        float *row = (SDR_FFT_ABLATE & 8) ? out + (size_t)blockIdx.x * N : live ? out + f * N : g.dummy;
         // ---- pass 2: radix R2, Ns = 16 ------------------------------------------------------
-        float2 y[B2][R2];
+        cf y[B2][R2];
 #pragma unroll
         for (int i = 0; i < B2; ++i) {
             const int j = tl + i * TPF;
-            float2 w2[R2 - 1];
+            cf w2[R2 - 1];
 #pragma unroll
             for (int t = 0; t < R2 - 1; ++t) w2[t] = tw2[(j & 15) * (R2 - 1) + t];
+            if constexpr (SDR_FFT_ABLATE & 1) {
+#pragma unroll
+                for (int t = 0; t < R2; ++t) y[i][t] = x[(i * R2 + t) & 15];
+            }
             pass_load<N, R2>(y[i], lds, j, w2);
         }
 
@@ -284,30 +353,36 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
                 const int j = tl + i * TPF;
                 const int base = (j >> 4) * (16 * R2) + (j & 15);
 #pragma unroll
-                for (int t = 0; t < R2; ++t) emit_db<N>(row, base + t * 16, y[i][t]);
+                for (int t = 0; t < R2; t += 2) emit_db2<N>(row, base + t * 16, base + (t + 1) * 16, y[i][t], y[i][t + 1]);
             }
             frame_sync<TPF>();                 // the slot's image is free for the next frame
         } else {
-            frame_sync<TPF>();                 // every lane has gathered its pass-2 inputs
+            if constexpr (!(SDR_FFT_ABLATE & 1)) {
+                    frame_sync<TPF>();             // every lane has gathered its pass-2 inputs
 #pragma unroll
-            for (int i = 0; i < B2; ++i) {
-                const int j = tl + i * TPF;
-                const int base = (j >> 4) * (16 * R2) + (j & 15);
+                for (int i = 0; i < B2; ++i) {
+                    const int j = tl + i * TPF;
+                    const int base = (j >> 4) * (16 * R2) + (j & 15);
 #pragma unroll
-                for (int t = 0; t < R2; ++t) lds[pidx(base + t * 16)] = y[i][t];
-            }
-            frame_sync<TPF>();  
+                    for (int t = 0; t < R2; ++t) lds[pidx(base + t * 16)] = y[i][t];
+                }
+                frame_sync<TPF>();
+                }
             // ---- pass 3: radix R3, Ns = 16*R2 ---------------------------------------------
 #pragma unroll
             for (int i = 0; i < B3; ++i) {
-                float2 z[R3];
+                cf z[R3];
                 const int j = tl + i * TPF;
+                if constexpr (SDR_FFT_ABLATE & 1) {
+#pragma unroll
+                    for (int t = 0; t < R3; ++t) z[t] = y[((i * R3 + t) / R2) % B2][(i * R3 + t) % R2];
+                }
                 pass_load<N, R3>(z, lds, j, w3[i]);
                 const int base = (j / Ns3) * (Ns3 * R3) + (j & (Ns3 - 1));
 #pragma unroll
-                for (int t = 0; t < R3; ++t) emit_db<N>(row, base + t * Ns3, z[t]);
+                for (int t = 0; t < R3; t += 2) emit_db2<N>(row, base + t * Ns3, base + (t + 1) * Ns3, z[t], z[t + 1]);
             }
-            frame_sync<TPF>();                 // the slot's image is free for the next frame
+            if constexpr (!(SDR_FFT_ABLATE & 1)) frame_sync<TPF>();   // the slot's image is free for the next frame
         }
     }
 }
@@ -351,8 +426,8 @@ int launch_fft(sdr_fft_plan *p, const int16_t *d_iq, long long n_in, float *d_ou
     const bool half = (p->hop * 2 == p->nfft);
 #define SDR_FFT(N, R2, R3)                                                                        \
     do {                                                                                          \
-        if (half) fft_db_kernel<N, R2, R3, true><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g); \
-        else fft_db_kernel<N, R2, R3, false><<<grid, 256, 0, st>>>(in, p->d_win, p->d_tw, d_out, g);     \
+        if (half) fft_db_kernel<N, R2, R3, true><<<grid, 256, 0, st>>>(in, p->d_win, (const cf *)p->d_tw, d_out, g); \
+        else fft_db_kernel<N, R2, R3, false><<<grid, 256, 0, st>>>(in, p->d_win, (const cf *)p->d_tw, d_out, g);     \
     } while (0)
     switch (p->nfft) {
     case 4096: SDR_FFT(4096, 16, 16); break;

@@ -836,6 +836,169 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     store_outputs<R>(g, outv, ch, M0 + 2LL * tid, y, ynext, M0 + g.per_tile);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fir_mfma_bf16_kernel: the same Toeplitz GEMM on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16,
+// 16x the float32 MFMA rate) WITHOUT giving up float32 accuracy: both operands are split into
+// bf16 pieces that represent them exactly,
+//   int16 sample  s = 256*(s >> 8) + (s & 255)        two pieces, each an 8-bit integer (x 2^8)
+//   float32 tap   h = h1 + h2 + h3                    three pieces of 8 significant bits
+// so the six piece products are exact in float32 and only the matrix unit's float32 accumulation
+// rounds -- as in the float32 kernels.  Six MFMAs of 16 cycles replace thirty-two of 32.
+//
+// Work split: a persistent 256-lane workgroup walks tiles of 512 outputs = 32 groups of 16 =
+// four column blocks of 16 columns (8 groups x {I, Q}).  The k range (window offsets, steps of
+// 32) is dealt to the four waves round-robin: wave w owns steps w, w+4, ... (at most 6) for ALL
+// column blocks, so its share of the tap matrix (6 steps x 3 pieces x 16 B per lane = 72 VGPRs)
+// is loaded once per kernel and the k loop reads only samples: one ds_read_b128 per (step, block,
+// piece) feeding three MFMAs.  The four partial sums meet in LDS (aliased onto the tile).
+//   A (taps):    lane (i = lane % 16, kq = lane / 16) holds H[i][32*ks + 8*kq + 0..7],
+//                H[i][k] = h[D*i + Tb - k] (Toeplitz skew lives here, so sample reads stay aligned)
+//   B (samples): lane (j, kq) holds samples 16*D*grp + 32*ks + 8*kq + 0..7 of plane (j & 1, piece)
+//   C:           lane (j, kq) holds outputs 4*kq + 0..3 of group grp = 8*cb + j/2, component j & 1
+// LDS: [I hi | Q hi | I lo | Q lo] bf16 planes (plane stride = 32 mod 256 bytes: the I and Q lanes
+// of one read land on different banks) | ybuf (513 float2).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kBfSteps = 6;        // k steps per wave (24 steps of 32 = windows up to 768 samples)
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// two exact floats -> their bf16 bit patterns packed (a low, b high)
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b)
+{
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+
+__global__ void __launch_bounds__(256, 2)
+fir_mfma_bf16_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
+                     const uint4 *__restrict__ atab, const FirGeom g, const int plane_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, kq = lane >> 4;
+    const int nks = g.ngran;                                   // k steps of 32 in the window
+    const int region = 4 * plane_bytes > 16384 ? 4 * plane_bytes : 16384;
+    float2 *ybuf = (float2 *)(smem + region);
+    // plane p = 2*piece + component; Q-first input swaps the component planes
+    const int cI = g.swap_iq ? 1 : 0, cQ = 1 - cI;
+
+    // this wave's share of the tap matrix, resident for the whole kernel
+    bf16x8 a[kBfSteps][3];
+#pragma unroll
+    for (int s = 0; s < kBfSteps; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[s][p] = as_bf16x8(atab[((wave * kBfSteps + s) * 3 + p) * 64 + lane]);
+
+    const int bofs = (j & 1) * plane_bytes + 2 * (16 * g.D * (j >> 1) + 8 * kq);   // hi plane of component j&1
+
+    for (int t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
+        const long long ch = t / g.tiles_per_ch;
+        const int tile = t - (int)ch * g.tiles_per_ch;
+        const long long M0 = g.tile0 + (long long)tile * g.per_tile;
+        const long long W0 = M0 * g.D - g.Tback;
+        const uint32_t *src = in + ch * g.in_stride;
+
+        // ---- stage: 4 samples per lane and round, split into the four planes ----------------
+        const bool interior = (W0 >= g.lo_valid) && (W0 + 4LL * g.s_gran <= g.hi_valid);
+        for (int k0 = 0; k0 < g.s_gran; k0 += 256 * 4) {
+            uint4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int sg = k0 + 256 * k + tid;
+                sg = sg < g.s_gran ? sg : g.s_gran - 1;
+                const long long sidx = W0 + 4LL * sg;
+                if (interior) {
+                    w[k] = *(const uint4 *)(src + sidx);
+                } else {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const long long si = sidx + u;
+                        e[u] = (si >= g.lo_valid && si < g.hi_valid) ? src[si] : 0u;
+                    }
+                    w[k] = make_uint4(e[0], e[1], e[2], e[3]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sg = k0 + 256 * k + tid;
+                if (sg < g.s_gran) {
+                    const uint32_t e[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+                    float ih[4], il[4], qh[4], ql[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ih[u] = (float)(short)(e[u] & 0xff00u);              // 256 * (I >> 8), exact
+                        il[u] = (float)(e[u] & 0xffu);                       // I & 255
+                        qh[u] = (float)((int)(e[u] & 0xff000000u) >> 16);    // 256 * (Q >> 8)
+                        ql[u] = (float)((e[u] >> 16) & 0xffu);               // Q & 255
+                    }
+                    unsigned char *dst = smem + 8 * sg;
+                    *(uint2 *)(dst + cI * plane_bytes) = make_uint2(pack_bf16(ih[0], ih[1]), pack_bf16(ih[2], ih[3]));
+                    *(uint2 *)(dst + cQ * plane_bytes) = make_uint2(pack_bf16(qh[0], qh[1]), pack_bf16(qh[2], qh[3]));
+                    *(uint2 *)(dst + (2 + cI) * plane_bytes) = make_uint2(pack_bf16(il[0], il[1]), pack_bf16(il[2], il[3]));
+                    *(uint2 *)(dst + (2 + cQ) * plane_bytes) = make_uint2(pack_bf16(ql[0], ql[1]), pack_bf16(ql[2], ql[3]));
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- k loop: this wave's steps, all four column blocks -------------------------------
+        f32x4 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < kBfSteps; ++s) {
+            const int ks = wave + 4 * s;
+            if (ks < nks) {                                    // wave-uniform
+                bf16x8 bh[4], bl[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const unsigned char *bp = smem + bofs + 2 * (16 * g.D * 8 * cb + 32 * ks);
+                    bh[cb] = as_bf16x8(*(const uint4 *)bp);
+                    bl[cb] = as_bf16x8(*(const uint4 *)(bp + 2 * plane_bytes));
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][p], bh[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][p], bl[cb], acc[cb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                       // every wave is done with the planes
+
+        // ---- meet the four partial sums (aliased onto the tile), hand outputs to ybuf --------
+        f32x4 *part = (f32x4 *)smem;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) part[(wave * 4 + cb) * 64 + lane] = acc[cb];
+        __syncthreads();
+        {
+            const int cb = wave;                               // lane (cb, lane) sums block cb
+            f32x4 v = part[cb * 64 + lane];
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) {
+                const f32x4 u = part[(w2 * 4 + cb) * 64 + lane];
+                v += u;
+            }
+            float *yb = (float *)ybuf + 2 * (16 * (8 * cb + (j >> 1)) + 4 * kq) + (j & 1);
+            yb[0] = v[0];
+            yb[2] = v[1];
+            yb[4] = v[2];
+            yb[6] = v[3];
+        }
+        __syncthreads();
+        const float2 y[2] = {ybuf[2 * tid], ybuf[2 * tid + 1]};
+        const float2 ynext = ybuf[2 * tid + 2];                // FM only; the last lane's is unused
+        store_outputs<2>(g, outv, ch, M0 + 2LL * tid, y, ynext, M0 + g.per_tile);
+        // the next tile's staging overwrites the partial sums (read before the last barrier) and,
+        // three barriers later, ybuf
+    }
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -847,6 +1010,9 @@ struct sdr_fir_plan {
     bool planar = false;    // fir_planar_kernel (float planes, convert once)
     bool mfma = false;      // fir_mfma_kernel (float planes, Toeplitz GEMM on the matrix cores)
     float4 *d_atab = nullptr;   // its A-operand table
+    bool mfma_bf16 = false; // fir_mfma_bf16_kernel (split-bf16 Toeplitz GEMM, persistent)
+    uint4 *d_atab16 = nullptr;  // its A-operand table (bf16 pieces)
+    int plane_bytes = 0;
     double scale, mix_fr;
     int spg;                // samples per LDS granule: 4 (raw) / 2 (stream)
     int Tback, Lw4, ngran, q, pad, s_gran, a_gran, n_inst, lds_bytes;
@@ -898,6 +1064,14 @@ template <int R>
 hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void *out,
                     const FirGeom &g, unsigned tiles, unsigned n_ch)
 {
+    if (p->mfma_bf16) {
+        if (p->lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)fir_mfma_bf16_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+        const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
+        fir_mfma_bf16_kernel<<<nb, 256, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab16, g, p->plane_bytes);
+        return hipGetLastError();
+    }
     if (p->mfma) {
         if (p->lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)fir_mfma_kernel,
@@ -1005,7 +1179,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->n_taps > 16384) { sdr::set_error("n_taps > 16384 unsupported"); return SDR_EINVAL; }
     if (d->input < SDR_IN_I16_IQ || d->input > SDR_IN_I8_IQ) { sdr::set_error("bad input kind"); return SDR_EINVAL; }
     if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_REAL) { sdr::set_error("bad mode"); return SDR_EINVAL; }
-    if (d->pipeline < 0 || d->pipeline > 4) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
+    if (d->pipeline < 0 || d->pipeline > 5) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
 
@@ -1014,7 +1188,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     p->scale = d->scale; p->mix_fr = d->mix_fr;
     (void)hipGetDevice(&p->device);
     const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0);
-    if ((d->pipeline == 1 || d->pipeline == 3 || d->pipeline == 4) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3 and 4 need int16 input without mixer"); return SDR_EINVAL; }
+    if ((d->pipeline == 1 || d->pipeline >= 3) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3, 4 and 5 need int16 input without mixer"); return SDR_EINVAL; }
     // Long filters (>= 32 MACs per input sample) are bound by VALU issue and, sustained, by the
     // power the conversions burn: the planar kernel converts once and runs T = 511 / D = 10 27 %
     // faster when the chip is warm (0.230 vs 0.292 ms per 2^26 samples); short filters are bound
@@ -1054,6 +1228,28 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         if (gm.lds_bytes > 160 * 1024) { delete p; sdr::set_error("pipeline 4: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); return SDR_EINVAL; }
         best = gm; bestR = 2; bestNT = 256; best_raw = true;
         p->mfma = true;
+    }
+    if (d->pipeline == 5) {
+        // split-bf16 Toeplitz GEMM: 256 lanes, 512 outputs per tile, k steps of 32 dealt to 4 waves
+        if (d->outputs_per_lane && d->outputs_per_lane != 2) { delete p; sdr::set_error("pipeline 5 has 2 outputs per lane"); return SDR_EINVAL; }
+        if (d->threads && d->threads != 256) { delete p; sdr::set_error("pipeline 5 has 256 threads"); return SDR_EINVAL; }
+        Geometry gm{};
+        gm.Tback = roundup(p->T - 1, 4);
+        const int W = gm.Tback + 15 * p->D + 1;
+        const int nks = (W + 31) / 32;
+        if (nks > 4 * kBfSteps) { delete p; sdr::set_error("pipeline 5: window of %d samples exceeds %d (decim=%d taps=%d)", W, 32 * 4 * kBfSteps, p->D, p->T); return SDR_EINVAL; }
+        gm.ngran = nks;                                     // k steps of 32
+        const long long s_tile = (long long)p->D * 16 * 31 + 32LL * nks;   // last group's base + its window
+        gm.s_gran = (int)(s_tile / 4);
+        gm.a_gran = gm.s_gran;
+        gm.n_inst = (gm.a_gran + 255) / 256;
+        gm.q = 1; gm.pad = 0;
+        p->plane_bytes = roundup((int)(2 * s_tile), 256) + 32;
+        const int region = 4 * p->plane_bytes > 16384 ? 4 * p->plane_bytes : 16384;
+        gm.lds_bytes = region + 513 * 8 + 8;
+        if (gm.lds_bytes > 160 * 1024) { delete p; sdr::set_error("pipeline 5: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); return SDR_EINVAL; }
+        best = gm; bestR = 2; bestNT = 256; best_raw = true;
+        p->mfma_bf16 = true;
     }
     if (!bestR && raw_possible && d->pipeline != 2) {
         const int pref_small[4] = {4, 2, 1, 8}, pref_large[4] = {2, 4, 1, 8};
@@ -1109,7 +1305,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                        d->decim, d->n_taps, d->outputs_per_lane, d->threads, d->pipeline);
         return SDR_EINVAL;
     }
-    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma; p->spg = best_raw ? 4 : 2;
+    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma && !p->mfma_bf16; p->spg = best_raw ? 4 : 2;
     p->Tback = best.Tback; p->Lw4 = best.Lw4; p->ngran = best.ngran; p->q = best.q; p->pad = best.pad;
     p->s_gran = best.s_gran; p->a_gran = best.a_gran; p->n_inst = best.n_inst; p->lds_bytes = best.lds_bytes;
     {
@@ -1121,6 +1317,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         if (per_cu > wave_cap) per_cu = wave_cap;
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
+        if (p->mfma_bf16 && per_cu > 3) per_cu = 3;          // 164 VGPRs (72 of them taps): three waves per SIMD
         p->stream_blocks = ncu * per_cu;
     }
 
@@ -1154,7 +1351,45 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 at[(size_t)q * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
     }
+    std::vector<uint4> at16;
+    if (p->mfma_bf16) {
+        // atab16[wave][s][piece][lane]: eight bf16 taps H[i][32*ks + 8*kq + c], ks = wave + 4*s,
+        // H[i][k] = h[D*i + Tb - k]; piece 0..2 of the exact split h = h1 + h2 + h3 (each the
+        // round-to-nearest bf16 of what the previous pieces left: 8 + 8 + 8 significant bits)
+        auto bf16_rne = [](float f) -> uint16_t {
+            uint32_t u; std::memcpy(&u, &f, 4);
+            if ((u & 0x7f800000u) == 0) return (uint16_t)(u >> 16 & 0x8000u);      // denormal -> signed zero
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto bf16_val = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        at16.assign((size_t)4 * kBfSteps * 3 * 64, make_uint4(0u, 0u, 0u, 0u));
+        for (int w = 0; w < 4; ++w)
+            for (int sidx = 0; sidx < kBfSteps; ++sidx)
+                for (int lane = 0; lane < 64; ++lane) {
+                    uint16_t pc[3][8];
+                    for (int c = 0; c < 8; ++c) {
+                        const long long k = 32LL * (w + 4 * sidx) + 8 * (lane >> 4) + c;
+                        const long long t = (long long)p->D * (lane & 15) + p->Tback - k;
+                        float r = (t >= 0 && t < p->T) ? hf[t] : 0.0f;
+                        for (int pi = 0; pi < 3; ++pi) {
+                            pc[pi][c] = bf16_rne(r);
+                            r -= bf16_val(pc[pi][c]);                        // exact: r loses its top 8 bits
+                        }
+                    }
+                    for (int pi = 0; pi < 3; ++pi) {
+                        uint4 v;
+                        v.x = pc[pi][0] | ((uint32_t)pc[pi][1] << 16);
+                        v.y = pc[pi][2] | ((uint32_t)pc[pi][3] << 16);
+                        v.z = pc[pi][4] | ((uint32_t)pc[pi][5] << 16);
+                        v.w = pc[pi][6] | ((uint32_t)pc[pi][7] << 16);
+                        at16[(((size_t)w * kBfSteps + sidx) * 3 + pi) * 64 + lane] = v;
+                    }
+                }
+    }
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
+    if (e == hipSuccess && p->mfma_bf16) e = hipMalloc((void **)&p->d_atab16, at16.size() * sizeof(uint4));
+    if (e == hipSuccess && p->mfma_bf16) e = hipMemcpy(p->d_atab16, at16.data(), at16.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess && p->mfma) e = hipMalloc((void **)&p->d_atab, at.size() * sizeof(float4));
     if (e == hipSuccess && p->mfma) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_gtab, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -1171,6 +1406,7 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (!p) return SDR_OK;
     if (p->d_gtab) (void)hipFree(p->d_gtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
+    if (p->d_atab16) (void)hipFree(p->d_atab16);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     delete p;
@@ -1203,7 +1439,7 @@ extern "C" int sdr_fir_plan_shape(const sdr_fir_plan *p, int *input, int *mode, 
 
 extern "C" int sdr_fir_plan_kernel(const sdr_fir_plan *p)
 {
-    return p ? (p->mfma ? 4 : (p->planar ? 3 : (p->raw ? 1 : 2))) : 0;
+    return p ? (p->mfma_bf16 ? 5 : (p->mfma ? 4 : (p->planar ? 3 : (p->raw ? 1 : 2)))) : 0;
 }
 
 extern "C" int sdr_fir_execute_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, void *d_out,

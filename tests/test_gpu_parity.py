@@ -176,7 +176,7 @@ def test_geometries_against_oracle(sdr, oracle, T, D):
     ran = 0
     for R in (1, 2, 4, 8):
         for NT in (64, 128, 256):
-            for pipe in (1, 2, 3, 4):   # raw tile / persistent float tiles / planar float tile / MFMA
+            for pipe in (1, 2, 3, 4, 5):   # raw tile / persistent float tiles / planar float tile / MFMA f32 / MFMA split bf16
                 try:
                     p_fm = sdr.FirPlan(h, D, mode=sdr.MODE_FM, outputs_per_lane=R, threads=NT,
                                        pipeline=pipe)
@@ -399,7 +399,7 @@ def test_wire_formats(sdr, oracle):
     fm = oracle.chain_i16(iq, D, h, oracle.MODE_FM)
     env = oracle.chain_i16(iq, D, h, oracle.MODE_ENV)
     assert np.array_equal(oracle.unpack_scale_i16_qi(qi), oracle.unpack_scale_i16(iq))
-    for pipe in (1, 2, 3, 4):
+    for pipe in (1, 2, 3, 4, 5):
         tag = f"QI pipe={pipe}"
         check_fm(sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I16_QI, pipeline=pipe).execute_host(qi),
                  fm, y, 1 / TWO_PI, tag)
@@ -602,3 +602,27 @@ def test_time_shard_beyond_2_pow_32_samples(sdr, oracle):
     with pytest.raises(sdr.SdrError) as e:
         plan.execute_range_dev(d_in, lo, n_res, n_total, ob - 10, sh.out_end, d_out)
     assert e.value.status == sdr.capi.ERANGE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D", [(511, 10), (511, 15), (300, 7), (64, 10)])
+def test_split_bf16_matrix_path_full_range(sdr, oracle, T, D):
+    """pipeline 5 splits int16 samples into two exact bf16 halves and the taps into three bf16
+    pieces: the whole int16 range (incl. -32768 and 32767, far beyond Q11) and taps of mixed
+    magnitude must come out at float32 accuracy, edges (zero history, ragged end) included"""
+    rng = np.random.default_rng(T + D)
+    n = 150_001
+    iq = rng.integers(-32768, 32768, 2 * n, dtype=np.int64).astype(np.int16)
+    iq[:8] = [-32768, 32767, 32767, -32768, -1, 255, 256, -256]
+    h = oracle.create_fir_filter(T, 0.7 / D, "hann") * rng.uniform(0.2, 1.0, T)   # no symmetry, mixed exponents
+    x = oracle.unpack_scale_i16(iq)
+    y = oracle.fir_decimate(x, D, h)
+    for mode, want in ((sdr.MODE_IQ, y), (sdr.MODE_ENV, np.abs(y))):
+        got = sdr.FirPlan(h, D, mode=mode, pipeline=5).execute_host(iq)
+        assert got.shape == want.shape
+        # full scale here is 16 (int16 * 2^-11); float32 accumulation of T products
+        assert np.abs(got.astype(want.dtype) - want).max() <= 1e-5 * 16 * 0.5, (T, D, mode)
+    fm = oracle.polar_discriminator(y, 1 / TWO_PI)
+    got = sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5).execute_host(iq)
+    check_fm(got, fm, y, 1 / TWO_PI, f"bf16 T={T} D={D}")
+    assert sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5).info()["kernel"] == "mfma_bf16"

@@ -183,7 +183,7 @@ class FirPlan:
         r, nt, lds = C.c_int(), C.c_int(), C.c_int()
         check(lib().sdr_fir_plan_info(self.h, C.byref(r), C.byref(nt), C.byref(lds)))
         return {"outputs_per_lane": r.value, "threads": nt.value, "lds_bytes": lds.value,
-                "kernel": {1: "raw_tile", 2: "stream", 3: "planar", 4: "mfma", 5: "mfma_bf16"}.get(lib().sdr_fir_plan_kernel(self.h), "?")}
+                "kernel": {1: "raw_tile", 2: "stream", 3: "planar", 4: "mfma", 5: "mfma_i8"}.get(lib().sdr_fir_plan_kernel(self.h), "?")}
 
     def out_count(self, n_in):
         return lib().sdr_fir_out_count(self.h, n_in)

@@ -837,165 +837,311 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 }
 
 // ---------------------------------------------------------------------------------------------
-// fir_mfma_bf16_kernel: the same Toeplitz GEMM on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16,
-// 16x the float32 MFMA rate) WITHOUT giving up float32 accuracy: both operands are split into
-// bf16 pieces that represent them exactly,
-//   int16 sample  s = 256*(s >> 8) + (s & 255)        two pieces, each an 8-bit integer (x 2^8)
-//   float32 tap   h = h1 + h2 + h3                    three pieces of 8 significant bits
-// so the six piece products are exact in float32 and only the matrix unit's float32 accumulation
-// rounds -- as in the float32 kernels.  Six MFMAs of 16 cycles replace thirty-two of 32.
+// fir_mfma_i8_kernel: the same Toeplitz GEMM on the int8 matrix pipe (v_mfma_i32_16x16x64_i8: twice
+// the bf16 rate, 32x the float32 MFMA rate) in EXACT integer arithmetic.  Both operands are
+// split into signed bytes:
+//   int16 sample  s = 256*hi + (lo' + 128)       hi = s >> 8,  lo' = (s & 255) - 128: the two raw
+//                                                 bytes of the sample, the low one with bit 7 flipped
+//   tap           h ~ q * 2^-F,  q = d3*2^24 + d2*2^16 + d1*2^8 + d0    balanced digits in [-128, 127]
+//                                                 (q has 31 bits: finer than the float32 taps of the other kernels)
+// Eight byte products per 64 window offsets accumulate in five int32 accumulators, one per weight
+// 2^(8w), w = digit + (hi ? 1 : 0), which are combined in float32 once per tile; the +128 of the low
+// bytes comes back as 128 * (sum of the row's digits), combined the same way.  No rounding happens
+// before that last step, and zero samples give exact zeros.
+// Staging is eight byte permutes per four samples -- no conversions.
 //
-// Work split: a persistent 256-lane workgroup walks tiles of 512 outputs = 32 groups of 16 =
-// four column blocks of 16 columns (8 groups x {I, Q}).  The k range (window offsets, steps of
-// 32) is dealt to the four waves round-robin: wave w owns steps w, w+4, ... (at most 6) for ALL
-// column blocks, so its share of the tap matrix (6 steps x 3 pieces x 16 B per lane = 72 VGPRs)
-// is loaded once per kernel and the k loop reads only samples: one ds_read_b128 per (step, block,
-// piece) feeding three MFMAs.  The four partial sums meet in LDS (aliased onto the tile).
-//   A (taps):    lane (i = lane % 16, kq = lane / 16) holds H[i][32*ks + 8*kq + 0..7],
-//                H[i][k] = h[D*i + Tb - k] (Toeplitz skew lives here, so sample reads stay aligned)
-//   B (samples): lane (j, kq) holds samples 16*D*grp + 32*ks + 8*kq + 0..7 of plane (j & 1, piece)
+// 768 lanes in two roles.  Waves 0-3 ("matrix waves", one per SIMD) only run k loops: the k range
+// (window offsets, steps of 64) is dealt to them round-robin, wave w owns steps w, w+4, w+8 for all
+// four column blocks (16 columns = 8 groups of 16 outputs x {I, Q}), so its share of the tap matrix
+// (3 steps x 4 digits x 16 B per lane = 48 VGPRs) is loaded once per kernel.  Waves 4-7 ("staging
+// waves") fetch the raw samples two tiles ahead, split them and stage the next tile into the other
+// LDS buffer; waves 8-11 ("finishing waves", two outputs per lane) finish the previous tile (sum
+// of the four matrix waves' partial results, discriminator / envelope, stores):
+//   phase p:  matrix: k loop of tile p-1    | staging: tile p -> buffer p&1,   | finishing: tile p-2
+//             (buffer (p-1)&1)              |          request tile p+2        |   from part
+//             barrier A
+//             matrix: partial sums of tile p-1 -> part      | (the others wait)
+//             barrier B
+// `part` is read by the finishing waves before A and written by the matrix waves between A and B.
+//   A (taps):    lane (i = lane % 16, kq = lane / 16) holds digit d of H[i][64*ks + 16*kq + 0..15],
+//                H[i][k] = q[D*i + Tb - k] (the Toeplitz skew lives here, so sample reads stay aligned)
+//   B (samples): lane (j, kq) holds bytes 16*D*grp + 64*ks + 16*kq + 0..15 of plane (j & 1, hi | lo)
 //   C:           lane (j, kq) holds outputs 4*kq + 0..3 of group grp = 8*cb + j/2, component j & 1
-// LDS: [I hi | Q hi | I lo | Q lo] bf16 planes (plane stride = 32 mod 256 bytes: the I and Q lanes
-// of one read land on different banks) | ybuf (513 float2).
+// (the order of the 64 k values inside a step only has to be the same in A and B).
+// LDS: 2 x [I hi | Q hi | I lo | Q lo] byte planes | part (4 waves x 4 blocks x 64 lanes x float4).
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kBfSteps = 6;        // k steps per wave (24 steps of 32 = windows up to 768 samples)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kI8Steps = 3;        // k steps per matrix wave (12 steps of 64 = windows up to 768 samples)
+constexpr int kI8Pre = 4;          // octets (8 samples) a staging lane fetches ahead: 4 x 256 x 8 samples per tile
 
-__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+#ifdef SDR_I8_ABLATE
+#define SDR_I8_ABL SDR_I8_ABLATE
+#else
+#define SDR_I8_ABL 0               // measurement builds: 1 no k loop, 2 no staging, 4 no epilogue
+#endif
 
-// two exact floats -> their bf16 bit patterns packed (a low, b high)
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b)
+__device__ __forceinline__ i32x4 as_i32x4(uint4 v) { return __builtin_bit_cast(i32x4, v); }
+
+// Workgroup barrier that orders LDS traffic only (__syncthreads() would also drain vmcnt, i.e. wait
+// for the helper waves' prefetch of the next tile).
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Staging fetches are branch-free: a quad (samples 4*quad .. 4*quad+3 of the tile) is always loaded
+// from an address clamped into the valid samples [lo, hi - 4] (tile-relative), so no load sits in
+// divergent control flow -- hipcc answers loads on two paths into the same registers with
+// s_waitcnt vmcnt(0) before every load, which serialises the HBM round trips.  Only tiles that
+// touch an end of the stream (wave-uniform test) then repair the quads in registers: samples
+// outside the stream read as zero.
+struct I8Tile {
+    const uint32_t *base;   // sample 0 of the tile (W0); may point before the buffer: only clamped offsets are dereferenced
+    int lo, hi;             // valid samples of the tile, tile-relative: [lo, hi)
+    bool edge;              // some staged sample is outside [lo, hi)
+};
+
+__device__ __forceinline__ I8Tile i8_tile(const FirGeom &g, const uint32_t *__restrict__ in, int t)
 {
-    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    const long long ch = t / g.tiles_per_ch;
+    const long long W0 = (g.tile0 + (long long)(t - (int)ch * g.tiles_per_ch) * g.per_tile) * g.D - g.Tback;
+    const long long n = 4LL * g.s_gran;
+    long long lo = g.lo_valid - W0, hi = g.hi_valid - W0;
+    lo = lo < 0 ? 0 : (lo > n ? n : lo);
+    hi = hi > n ? n : (hi < lo ? lo : hi);
+    I8Tile r;
+    r.base = in + ch * g.in_stride + W0;
+    r.lo = (int)lo;
+    r.hi = (int)hi;
+    r.edge = lo > 0 || hi < n;
+    return r;
 }
 
-__global__ void __launch_bounds__(256, 2)
-fir_mfma_bf16_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
-                     const uint4 *__restrict__ atab, const FirGeom g, const int plane_bytes)
+__device__ __forceinline__ int i8_clamped(const I8Tile &tl, int rel)
+{
+    const int top = tl.hi - 4 > tl.lo ? tl.hi - 4 : tl.lo;     // the host refuses streams shorter than 4 samples
+    return rel < tl.lo ? tl.lo : (rel > top ? top : rel);
+}
+
+__device__ __forceinline__ uint4 i8_fetch(const I8Tile &tl, int quad, int n_quads)
+{
+    quad = quad < n_quads ? quad : n_quads - 1;
+    return *(const uint4 *)(tl.base + i8_clamped(tl, 4 * quad));
+}
+
+// edge tiles: w was loaded at the clamped position; pick / zero the samples the quad asked for
+__device__ __forceinline__ uint4 i8_repair(const I8Tile &tl, int quad, int n_quads, uint4 w)
+{
+    quad = quad < n_quads ? quad : n_quads - 1;
+    const int rel = 4 * quad, at = i8_clamped(tl, rel);
+    const uint32_t e[4] = {w.x, w.y, w.z, w.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int si = rel + u, idx = si - at;
+        uint32_t v = e[0];
+        v = idx == 1 ? e[1] : v;
+        v = idx == 2 ? e[2] : v;
+        v = idx == 3 ? e[3] : v;
+        o[u] = (si >= tl.lo && si < tl.hi && idx >= 0 && idx < 4) ? v : 0u;
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// four samples (I | Q << 16 each) -> one dword per byte plane: {I lo', I hi, Q lo', Q hi}
+__device__ __forceinline__ void i8_split4(uint4 w, uint32_t &il, uint32_t &ih, uint32_t &ql, uint32_t &qh)
+{
+    // v_perm_b32(s0, s1, sel): byte n of {s0 (7..4), s1 (3..0)}
+    const uint32_t a01 = __builtin_amdgcn_perm(w.y, w.x, 0x05010400u);   // I0l I1l I0h I1h
+    const uint32_t a23 = __builtin_amdgcn_perm(w.w, w.z, 0x05010400u);
+    const uint32_t c01 = __builtin_amdgcn_perm(w.y, w.x, 0x07030602u);   // Q0l Q1l Q0h Q1h
+    const uint32_t c23 = __builtin_amdgcn_perm(w.w, w.z, 0x07030602u);
+    il = __builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u;
+    ih = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+    ql = __builtin_amdgcn_perm(c23, c01, 0x05040100u) ^ 0x80808080u;
+    qh = __builtin_amdgcn_perm(c23, c01, 0x07060302u);
+}
+
+// NSTEPS = k steps per matrix wave = ceil(steps in the window / 4).  Steps past the window carry
+// zero taps (the staged tile covers 4*NSTEPS steps, so their sample reads stay inside it); only the
+// last step is skipped by the waves that do not own a real one.
+template <int NSTEPS>
+__global__ void __launch_bounds__(768, 1)
+fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
+                   const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
+                   const int plane_bytes, const float yscale)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int j = lane & 15, kq = lane >> 4;
-    const int nks = g.ngran;                                   // k steps of 32 in the window
-    const int region = 4 * plane_bytes > 16384 ? 4 * plane_bytes : 16384;
-    float2 *ybuf = (float2 *)(smem + region);
-    // plane p = 2*piece + component; Q-first input swaps the component planes
-    const int cI = g.swap_iq ? 1 : 0, cQ = 1 - cI;
+    const bool matrix = tid < 256;
+    const int buf_bytes = 4 * plane_bytes;
+    f32x4 *part = (f32x4 *)(smem + 2 * buf_bytes);             // [wave][column block][lane]
+    const int n_t = (g.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // this workgroup's tiles
 
-    // this wave's share of the tap matrix, resident for the whole kernel
-    bf16x8 a[kBfSteps][3];
+    if (matrix) {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int j = lane & 15, kq = lane >> 4;
+        const bool last_real = wave + 4 * (NSTEPS - 1) < g.ngran;   // does this wave own a real last step?
+        // 128 * (sum of this wave's digits of each output row), combined over the digits exactly as the
+        // accumulators are below: it undoes the -128 of the low bytes, and because the combination
+        // is the same sequence of float32 operations on the negated integers, zero samples still
+        // give an exact zero
+        const f32x4 bias = __builtin_bit_cast(f32x4, btab[wave * 64 + lane]);
+        // this wave's share of the tap matrix, resident for the whole kernel
+        i32x4 a[NSTEPS][4];
 #pragma unroll
-    for (int s = 0; s < kBfSteps; ++s)
+        for (int s = 0; s < NSTEPS; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[s][p] = as_bf16x8(atab[((wave * kBfSteps + s) * 3 + p) * 64 + lane]);
-
-    const int bofs = (j & 1) * plane_bytes + 2 * (16 * g.D * (j >> 1) + 8 * kq);   // hi plane of component j&1
-
-    for (int t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
-        const long long ch = t / g.tiles_per_ch;
-        const int tile = t - (int)ch * g.tiles_per_ch;
-        const long long M0 = g.tile0 + (long long)tile * g.per_tile;
-        const long long W0 = M0 * g.D - g.Tback;
-        const uint32_t *src = in + ch * g.in_stride;
-
-        // ---- stage: 4 samples per lane and round, split into the four planes ----------------
-        const bool interior = (W0 >= g.lo_valid) && (W0 + 4LL * g.s_gran <= g.hi_valid);
-        for (int k0 = 0; k0 < g.s_gran; k0 += 256 * 4) {
-            uint4 w[4];
+            for (int d = 0; d < 4; ++d) a[s][d] = as_i32x4(atab[((wave * kI8Steps + s) * 4 + d) * 64 + lane]);
+        // hi plane of component j&1, this lane's group within a column block, this wave's step 0
+        const int bofs = (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq + 64 * wave;
+        const int cb_bytes = 16 * g.D * 8;                     // between column blocks
+        for (int p = 0; p <= n_t + 1; ++p) {
+            const bool work = p >= 1 && p <= n_t;
+            f32x4 res[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int sg = k0 + 256 * k + tid;
-                sg = sg < g.s_gran ? sg : g.s_gran - 1;
-                const long long sidx = W0 + 4LL * sg;
-                if (interior) {
-                    w[k] = *(const uint4 *)(src + sidx);
-                } else {
-                    uint32_t e[4];
+            for (int cb = 0; cb < 4; ++cb) res[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (work && !(SDR_I8_ABL & 1)) {
+                const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs;
+                // units of (column block, step), samples requested one unit ahead
+                i32x4 b[2][2];                                 // [buffer][hi, lo]
+                constexpr int UNITS = 4 * NSTEPS;
+                b[0][0] = as_i32x4(*(const uint4 *)bbase);
+                b[0][1] = as_i32x4(*(const uint4 *)(bbase + 2 * plane_bytes));
+                i32x4 acc[5];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const long long si = sidx + u;
-                        e[u] = (si >= g.lo_valid && si < g.hi_valid) ? src[si] : 0u;
+                for (int u = 0; u < UNITS; ++u) {
+                    const int cb = u / NSTEPS, s = u % NSTEPS;
+                    if (u + 1 < UNITS) {
+                        const unsigned char *bp = bbase + ((u + 1) / NSTEPS) * cb_bytes + 64 * 4 * ((u + 1) % NSTEPS);
+                        b[(u + 1) & 1][0] = as_i32x4(*(const uint4 *)bp);
+                        b[(u + 1) & 1][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
                     }
-                    w[k] = make_uint4(e[0], e[1], e[2], e[3]);
-                }
-            }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int sg = k0 + 256 * k + tid;
-                if (sg < g.s_gran) {
-                    const uint32_t e[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
-                    float ih[4], il[4], qh[4], ql[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        ih[u] = (float)(short)(e[u] & 0xff00u);              // 256 * (I >> 8), exact
-                        il[u] = (float)(e[u] & 0xffu);                       // I & 255
-                        qh[u] = (float)((int)(e[u] & 0xff000000u) >> 16);    // 256 * (Q >> 8)
-                        ql[u] = (float)((e[u] >> 16) & 0xffu);               // Q & 255
+                        for (int w = 0; w < 5; ++w) acc[w] = i32x4{0, 0, 0, 0};
                     }
-                    unsigned char *dst = smem + 8 * sg;
-                    *(uint2 *)(dst + cI * plane_bytes) = make_uint2(pack_bf16(ih[0], ih[1]), pack_bf16(ih[2], ih[3]));
-                    *(uint2 *)(dst + cQ * plane_bytes) = make_uint2(pack_bf16(qh[0], qh[1]), pack_bf16(qh[2], qh[3]));
-                    *(uint2 *)(dst + (2 + cI) * plane_bytes) = make_uint2(pack_bf16(il[0], il[1]), pack_bf16(il[2], il[3]));
-                    *(uint2 *)(dst + (2 + cQ) * plane_bytes) = make_uint2(pack_bf16(ql[0], ql[1]), pack_bf16(ql[2], ql[3]));
+                    if (s < NSTEPS - 1 || last_real) {         // wave-uniform
+                        const i32x4 xh = b[u & 1][0], xl = b[u & 1][1];
+                        // weight w = digit + (hi ? 1 : 0); no accumulator twice in a row
+                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][0], xl, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][1], xl, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xl, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][3], xl, acc[3], 0, 0, 0);
+                        acc[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][3], xh, acc[4], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][0], xh, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][1], xh, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xh, acc[3], 0, 0, 0);
+                    }
+                    if (s == NSTEPS - 1) {
+                        // sum of 2^(8w) * acc[w] in float32, top weight first (balanced digits: the top
+                        // term carries the value, the rest are corrections -- nothing cancels)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = (float)acc[4][r];
+                            v = __fmaf_rn(v, 256.0f, (float)acc[3][r]);
+                            v = __fmaf_rn(v, 256.0f, (float)acc[2][r]);
+                            v = __fmaf_rn(v, 256.0f, (float)acc[1][r]);
+                            v = __fmaf_rn(v, 256.0f, (float)acc[0][r]);
+                            res[cb][r] = v + bias[r];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        }
-        __syncthreads();
-
-        // ---- k loop: this wave's steps, all four column blocks -------------------------------
-        f32x4 acc[4];
+            lds_only_barrier();                                // A
+            if (work) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < kBfSteps; ++s) {
-            const int ks = wave + 4 * s;
-            if (ks < nks) {                                    // wave-uniform
-                bf16x8 bh[4], bl[4];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    const unsigned char *bp = smem + bofs + 2 * (16 * g.D * 8 * cb + 32 * ks);
-                    bh[cb] = as_bf16x8(*(const uint4 *)bp);
-                    bl[cb] = as_bf16x8(*(const uint4 *)(bp + 2 * plane_bytes));
-                }
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb)
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][p], bh[cb], acc[cb], 0, 0, 0);
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb)
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][p], bl[cb], acc[cb], 0, 0, 0);
-                }
+                for (int cb = 0; cb < 4; ++cb) part[(wave * 4 + cb) * 64 + lane] = res[cb];
             }
+            lds_only_barrier();                                // B
         }
-        __syncthreads();                                       // every wave is done with the planes
-
-        // ---- meet the four partial sums (aliased onto the tile), hand outputs to ybuf --------
-        f32x4 *part = (f32x4 *)smem;
+    } else if (tid < 512) {
+        // ================= staging waves: fetch, split, stage =================================
+        const int st = tid - 256;                              // 0..255
+        const int cI = g.swap_iq ? 1 : 0;                      // Q-first input swaps the component planes
+        const int n_oct = (g.s_gran + 1) / 2;                  // octets per tile
+        // raw samples of two tiles travel at any time: set p&1 holds tile p until it is staged in
+        // phase p and is then refilled with tile p+2 (one tile ahead did not cover the HBM latency).
+        // These waves issue no stores, so waiting for a set never waits for anything else.
+        uint4 w0[kI8Pre][2], w1[kI8Pre][2];
+        auto request = [&](int n, uint4 (&w)[kI8Pre][2]) {     // n-th tile of this workgroup
+            // unconditional (past the end: the last tile again, unused): a skipped request would make
+            // the registers conditionally defined and hipcc would copy them right after the loads
+            n = n < n_t ? n : n_t - 1;
+            const I8Tile tl = i8_tile(g, in, blockIdx.x + n * gridDim.x);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) part[(wave * 4 + cb) * 64 + lane] = acc[cb];
-        __syncthreads();
-        {
-            const int cb = wave;                               // lane (cb, lane) sums block cb
-            f32x4 v = part[cb * 64 + lane];
+            for (int k = 0; k < kI8Pre; ++k)
 #pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) {
-                const f32x4 u = part[(w2 * 4 + cb) * 64 + lane];
-                v += u;
+                for (int h = 0; h < 2; ++h) w[k][h] = i8_fetch(tl, 2 * (256 * k + st) + h, g.s_gran);
+        };
+        auto phase = [&](int p, uint4 (&w)[kI8Pre][2]) {
+            if (p < n_t && !(SDR_I8_ABL & 2)) {
+                unsigned char *buf = smem + (p & 1) * buf_bytes;
+                const I8Tile tl = i8_tile(g, in, blockIdx.x + p * gridDim.x);
+                auto put = [&](int oct, uint4 q0, uint4 q1) {
+                    if (tl.edge) {                             // wave-uniform
+                        q0 = i8_repair(tl, 2 * oct, g.s_gran, q0);
+                        q1 = i8_repair(tl, 2 * oct + 1, g.s_gran, q1);
+                    }
+                    uint32_t il[2], ih[2], ql[2], qh[2];
+                    i8_split4(q0, il[0], ih[0], ql[0], qh[0]);
+                    i8_split4(q1, il[1], ih[1], ql[1], qh[1]);
+                    unsigned char *dst = buf + 8 * oct;
+                    *(uint2 *)(dst + cI * plane_bytes) = make_uint2(ih[0], ih[1]);
+                    *(uint2 *)(dst + (1 - cI) * plane_bytes) = make_uint2(qh[0], qh[1]);
+                    *(uint2 *)(dst + (2 + cI) * plane_bytes) = make_uint2(il[0], il[1]);
+                    *(uint2 *)(dst + (3 - cI) * plane_bytes) = make_uint2(ql[0], ql[1]);
+                };
+#pragma unroll
+                for (int k = 0; k < kI8Pre; ++k)
+                    if (256 * k + st < n_oct) put(256 * k + st, w[k][0], w[k][1]);
+                for (int oct = 256 * kI8Pre + st; oct < n_oct; oct += 256)     // very wide tiles only
+                    put(oct, i8_fetch(tl, 2 * oct, g.s_gran), i8_fetch(tl, 2 * oct + 1, g.s_gran));
             }
-            float *yb = (float *)ybuf + 2 * (16 * (8 * cb + (j >> 1)) + 4 * kq) + (j & 1);
-            yb[0] = v[0];
-            yb[2] = v[1];
-            yb[4] = v[2];
-            yb[6] = v[3];
+            request(p + 2, w);
+            lds_only_barrier();                                // A
+            lds_only_barrier();                                // B
+        };
+        request(0, w0);
+        request(1, w1);
+        for (int p = 0; p <= n_t + 1; p += 2) {
+            phase(p, w0);
+            if (p + 1 <= n_t + 1) phase(p + 1, w1);
         }
-        __syncthreads();
-        const float2 y[2] = {ybuf[2 * tid], ybuf[2 * tid + 1]};
-        const float2 ynext = ybuf[2 * tid + 2];                // FM only; the last lane's is unused
-        store_outputs<2>(g, outv, ch, M0 + 2LL * tid, y, ynext, M0 + g.per_tile);
-        // the next tile's staging overwrites the partial sums (read before the last barrier) and,
-        // three barriers later, ybuf
+    } else {
+        // ================= finishing waves: partial sums -> epilogue -> stores ==================
+        const int ft = tid - 512;                              // 0..255: outputs 2*ft, 2*ft+1 of the tile
+        // where outputs 2*ft, 2*ft+1 (one float2) and, for the discriminator, 2*ft+2 sit in `part`:
+        // output o = 16*grp + i is element i&3 of lane (i>>2)*16 + 2*(grp&7) + component, block grp>>3
+        const int o0 = 2 * ft, o2 = o0 + 2 < 512 ? o0 + 2 : 511;
+        const float *pa = (const float *)(part + (o0 >> 7) * 64 + ((o0 & 15) >> 2) * 16 + 2 * ((o0 >> 4) & 7)) + (o0 & 3);
+        const float *pb = (const float *)(part + (o2 >> 7) * 64 + ((o2 & 15) >> 2) * 16 + 2 * ((o2 >> 4) & 7)) + (o2 & 3);
+        for (int p = 0; p <= n_t + 1; ++p) {
+            if (p >= 2 && !(SDR_I8_ABL & 4)) {
+                const int t = blockIdx.x + (p - 2) * gridDim.x;
+                const long long ch = t / g.tiles_per_ch;
+                const long long M0 = g.tile0 + (long long)(t - (int)ch * g.tiles_per_ch) * g.per_tile;
+                float2 v[2][4];                                // [component][wave]: outputs o0, o0+1
+                float z[2][4];                                 //                     output o2
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) {
+                        v[c][wv] = *(const float2 *)(pa + (wv * 4 * 64 + c) * 4);
+                        z[c][wv] = pb[(wv * 4 * 64 + c) * 4];
+                    }
+                // one summation order for every output; then the power-of-two scale
+                float2 y[2], ynext;
+                y[0] = make_float2((((v[0][0].x + v[0][1].x) + v[0][2].x) + v[0][3].x) * yscale,
+                                   (((v[1][0].x + v[1][1].x) + v[1][2].x) + v[1][3].x) * yscale);
+                y[1] = make_float2((((v[0][0].y + v[0][1].y) + v[0][2].y) + v[0][3].y) * yscale,
+                                   (((v[1][0].y + v[1][1].y) + v[1][2].y) + v[1][3].y) * yscale);
+                ynext = make_float2((((z[0][0] + z[0][1]) + z[0][2]) + z[0][3]) * yscale,
+                                    (((z[1][0] + z[1][1]) + z[1][2]) + z[1][3]) * yscale);
+                store_outputs<2>(g, outv, ch, M0 + 2LL * ft, y, ynext, M0 + g.per_tile);
+            }
+            lds_only_barrier();                                // A
+            lds_only_barrier();                                // B
+        }
     }
 }
 
@@ -1010,9 +1156,11 @@ struct sdr_fir_plan {
     bool planar = false;    // fir_planar_kernel (float planes, convert once)
     bool mfma = false;      // fir_mfma_kernel (float planes, Toeplitz GEMM on the matrix cores)
     float4 *d_atab = nullptr;   // its A-operand table
-    bool mfma_bf16 = false; // fir_mfma_bf16_kernel (split-bf16 Toeplitz GEMM, persistent)
-    uint4 *d_atab16 = nullptr;  // its A-operand table (bf16 pieces)
+    bool mfma_i8 = false;   // fir_mfma_i8_kernel (byte-split Toeplitz GEMM on the int8 matrix pipe, persistent)
+    uint4 *d_atab8 = nullptr;   // its A-operand table (tap digits)
+    uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave
     int plane_bytes = 0;
+    float yscale = 1.f;         // its output scale 2^-(F+11)
     double scale, mix_fr;
     int spg;                // samples per LDS granule: 4 (raw) / 2 (stream)
     int Tback, Lw4, ngran, q, pad, s_gran, a_gran, n_inst, lds_bytes;
@@ -1064,12 +1212,22 @@ template <int R>
 hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void *out,
                     const FirGeom &g, unsigned tiles, unsigned n_ch)
 {
-    if (p->mfma_bf16) {
-        if (p->lds_bytes > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)fir_mfma_bf16_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+    if (p->mfma_i8) {
         const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
-        fir_mfma_bf16_kernel<<<nb, 256, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab16, g, p->plane_bytes);
+#define SDR_I8(NS)                                                                               \
+    do {                                                                                         \
+        if (p->lds_bytes > 64 * 1024)                                                            \
+            (void)hipFuncSetAttribute((const void *)fir_mfma_i8_kernel<NS>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes); \
+        fir_mfma_i8_kernel<NS><<<nb, 768, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
+                                                              p->plane_bytes, p->yscale);                \
+    } while (0)
+        switch ((p->ngran + 3) / 4) {
+        case 1: SDR_I8(1); break;
+        case 2: SDR_I8(2); break;
+        default: SDR_I8(3); break;
+        }
+#undef SDR_I8
         return hipGetLastError();
     }
     if (p->mfma) {
@@ -1128,6 +1286,7 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.out_stride = out_stride;
     g.lo_valid = in_first > 0 ? in_first : 0;
     g.hi_valid = (in_first + n_resident < n_total) ? in_first + n_resident : n_total;
+    if (p->mfma_i8 && g.hi_valid - g.lo_valid < 4) { sdr::set_error("pipeline 5 needs at least 4 resident samples"); return SDR_EINVAL; }
     g.tile0 = out_begin & ~3LL;
     g.out_begin = out_begin;
     g.out_end = out_end;
@@ -1225,31 +1384,53 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         gm.n_inst = (gm.a_gran + 255) / 256;
         gm.q = 1; gm.pad = 0;
         gm.lds_bytes = gm.a_gran * 32 + 513 * 8 + 8;
-        if (gm.lds_bytes > 160 * 1024) { delete p; sdr::set_error("pipeline 4: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); return SDR_EINVAL; }
+        if (gm.lds_bytes > 160 * 1024) { sdr::set_error("pipeline 4: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); delete p; return SDR_EINVAL; }
         best = gm; bestR = 2; bestNT = 256; best_raw = true;
         p->mfma = true;
     }
     if (d->pipeline == 5) {
-        // split-bf16 Toeplitz GEMM: 256 lanes, 512 outputs per tile, k steps of 32 dealt to 4 waves
-        if (d->outputs_per_lane && d->outputs_per_lane != 2) { delete p; sdr::set_error("pipeline 5 has 2 outputs per lane"); return SDR_EINVAL; }
-        if (d->threads && d->threads != 256) { delete p; sdr::set_error("pipeline 5 has 256 threads"); return SDR_EINVAL; }
+        // byte-split Toeplitz GEMM: 512 outputs per tile, k steps of 64 dealt to 4 matrix waves
+        if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 has one geometry (512 outputs per tile, 768 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
         Geometry gm{};
         gm.Tback = roundup(p->T - 1, 4);
         const int W = gm.Tback + 15 * p->D + 1;
-        const int nks = (W + 31) / 32;
-        if (nks > 4 * kBfSteps) { delete p; sdr::set_error("pipeline 5: window of %d samples exceeds %d (decim=%d taps=%d)", W, 32 * 4 * kBfSteps, p->D, p->T); return SDR_EINVAL; }
-        gm.ngran = nks;                                     // k steps of 32
-        const long long s_tile = (long long)p->D * 16 * 31 + 32LL * nks;   // last group's base + its window
-        gm.s_gran = (int)(s_tile / 4);
+        const int nks = (W + 63) / 64;
+        if (nks > 4 * kI8Steps) { sdr::set_error("pipeline 5: window of %d samples exceeds %d (decim=%d taps=%d)", W, 64 * 4 * kI8Steps, p->D, p->T); delete p; return SDR_EINVAL; }
+        gm.ngran = nks;                                     // k steps of 64
+        const long long s_tile = (long long)p->D * 16 * 31 + 64LL * 4 * ((nks + 3) / 4);   // last group's base + every wave's steps
+        gm.s_gran = (int)(s_tile / 4);                      // quads of samples staged
         gm.a_gran = gm.s_gran;
         gm.n_inst = (gm.a_gran + 255) / 256;
         gm.q = 1; gm.pad = 0;
-        p->plane_bytes = roundup((int)(2 * s_tile), 256) + 32;
-        const int region = 4 * p->plane_bytes > 16384 ? 4 * p->plane_bytes : 16384;
-        gm.lds_bytes = region + 513 * 8 + 8;
-        if (gm.lds_bytes > 160 * 1024) { delete p; sdr::set_error("pipeline 5: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); return SDR_EINVAL; }
-        best = gm; bestR = 2; bestNT = 256; best_raw = true;
-        p->mfma_bf16 = true;
+        // byte planes, 1 B per sample; the offset between the I and Q planes is chosen so that the
+        // 16-lane groups of the matrix waves' ds_read_b128 (MI355X_MICROARCH.md, LDS) meet no bank twice
+        {
+            static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                           {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                           {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                           {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+            const int base = roundup((int)s_tile, 256);
+            int best_skew = 0, best_cost = 1 << 30;
+            for (int skew = 0; skew < 256; skew += 16) {
+                int cost = 0;
+                for (int gi = 0; gi < 4; ++gi) {
+                    int per_slot[16] = {0}, worst = 0;
+                    for (int li = 0; li < 16; ++li) {
+                        const int lane = grp[gi][li], jj = lane & 15, kq = lane >> 4;
+                        const int addr = (jj & 1) * (base + skew) + 16 * p->D * (jj >> 1) + 16 * kq;
+                        const int slot = (addr / 16) & 15;
+                        if (++per_slot[slot] > worst) worst = per_slot[slot];
+                    }
+                    cost += worst;
+                }
+                if (cost < best_cost) { best_cost = cost; best_skew = skew; }
+            }
+            p->plane_bytes = base + best_skew;
+        }
+        gm.lds_bytes = 2 * 4 * p->plane_bytes + 16384;        // two tile buffers + the partial sums
+        if (gm.lds_bytes > 160 * 1024) { sdr::set_error("pipeline 5: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); delete p; return SDR_EINVAL; }
+        best = gm; bestR = 2; bestNT = 256; best_raw = true;   // 256 finishing lanes, two outputs each
+        p->mfma_i8 = true;
     }
     if (!bestR && raw_possible && d->pipeline != 2) {
         const int pref_small[4] = {4, 2, 1, 8}, pref_large[4] = {2, 4, 1, 8};
@@ -1305,7 +1486,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                        d->decim, d->n_taps, d->outputs_per_lane, d->threads, d->pipeline);
         return SDR_EINVAL;
     }
-    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma && !p->mfma_bf16; p->spg = best_raw ? 4 : 2;
+    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma && !p->mfma_i8; p->spg = best_raw ? 4 : 2;
     p->Tback = best.Tback; p->Lw4 = best.Lw4; p->ngran = best.ngran; p->q = best.q; p->pad = best.pad;
     p->s_gran = best.s_gran; p->a_gran = best.a_gran; p->n_inst = best.n_inst; p->lds_bytes = best.lds_bytes;
     {
@@ -1317,7 +1498,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         if (per_cu > wave_cap) per_cu = wave_cap;
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
-        if (p->mfma_bf16 && per_cu > 3) per_cu = 3;          // 164 VGPRs (72 of them taps): three waves per SIMD
+        if (p->mfma_i8) per_cu = 1;                           // 768 lanes, one matrix wave per SIMD
         p->stream_blocks = ncu * per_cu;
     }
 
@@ -1351,45 +1532,66 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 at[(size_t)q * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
     }
-    std::vector<uint4> at16;
-    if (p->mfma_bf16) {
-        // atab16[wave][s][piece][lane]: eight bf16 taps H[i][32*ks + 8*kq + c], ks = wave + 4*s,
-        // H[i][k] = h[D*i + Tb - k]; piece 0..2 of the exact split h = h1 + h2 + h3 (each the
-        // round-to-nearest bf16 of what the previous pieces left: 8 + 8 + 8 significant bits)
-        auto bf16_rne = [](float f) -> uint16_t {
-            uint32_t u; std::memcpy(&u, &f, 4);
-            if ((u & 0x7f800000u) == 0) return (uint16_t)(u >> 16 & 0x8000u);      // denormal -> signed zero
-            u += 0x7fffu + ((u >> 16) & 1u);
-            return (uint16_t)(u >> 16);
-        };
-        auto bf16_val = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
-        at16.assign((size_t)4 * kBfSteps * 3 * 64, make_uint4(0u, 0u, 0u, 0u));
+    std::vector<uint4> at8, bt8;
+    if (p->mfma_i8) {
+        // taps as 31-bit fixed point q = round(h * 2^F), F from the largest tap, in four balanced
+        // base-256 digits; atab8[wave][s][digit][lane] = sixteen digits of H[i][64*ks + 16*kq + c],
+        // ks = wave + 4*s, H[i][k] = q[D*i + Tb - k]
+        double hmax = 0.0;
+        for (int i = 0; i < p->T; ++i) hmax = std::fmax(hmax, std::fabs(d->taps[i]));
+        int e2 = 0;
+        if (hmax > 0.0) (void)std::frexp(hmax, &e2);           // hmax = m * 2^e2, 0.5 <= m < 1
+        const int F = 30 - e2;                                 // |q| <= 2^30
+        std::vector<long long> q(p->T);
+        for (int i = 0; i < p->T; ++i) q[i] = std::llround(std::ldexp(d->taps[i], F));
+        p->yscale = (float)std::ldexp(1.0, -(F + 11));         // Q11 samples
+        std::vector<int> rowsum((size_t)4 * 4 * 16, 0);        // [wave][digit][row]
+        at8.assign((size_t)4 * kI8Steps * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
         for (int w = 0; w < 4; ++w)
-            for (int sidx = 0; sidx < kBfSteps; ++sidx)
+            for (int sidx = 0; sidx < kI8Steps; ++sidx)
                 for (int lane = 0; lane < 64; ++lane) {
-                    uint16_t pc[3][8];
-                    for (int c = 0; c < 8; ++c) {
-                        const long long k = 32LL * (w + 4 * sidx) + 8 * (lane >> 4) + c;
+                    unsigned char dg[4][16];
+                    for (int c = 0; c < 16; ++c) {
+                        const long long k = 64LL * (w + 4 * sidx) + 16 * (lane >> 4) + c;
                         const long long t = (long long)p->D * (lane & 15) + p->Tback - k;
-                        float r = (t >= 0 && t < p->T) ? hf[t] : 0.0f;
-                        for (int pi = 0; pi < 3; ++pi) {
-                            pc[pi][c] = bf16_rne(r);
-                            r -= bf16_val(pc[pi][c]);                        // exact: r loses its top 8 bits
+                        long long r = (t >= 0 && t < p->T) ? q[t] : 0;
+                        for (int di = 0; di < 4; ++di) {
+                            const long long dgt = ((r + 128) & 255) - 128;       // balanced digit in [-128, 127]
+                            dg[di][c] = (unsigned char)(dgt & 255);
+                            rowsum[((size_t)w * 4 + di) * 16 + (lane & 15)] += (int)dgt;
+                            r = (r - dgt) / 256;
                         }
                     }
-                    for (int pi = 0; pi < 3; ++pi) {
-                        uint4 v;
-                        v.x = pc[pi][0] | ((uint32_t)pc[pi][1] << 16);
-                        v.y = pc[pi][2] | ((uint32_t)pc[pi][3] << 16);
-                        v.z = pc[pi][4] | ((uint32_t)pc[pi][5] << 16);
-                        v.w = pc[pi][6] | ((uint32_t)pc[pi][7] << 16);
-                        at16[(((size_t)w * kBfSteps + sidx) * 3 + pi) * 64 + lane] = v;
+                    for (int di = 0; di < 4; ++di) {
+                        uint32_t v[4];
+                        for (int u = 0; u < 4; ++u)
+                            v[u] = dg[di][4 * u] | ((uint32_t)dg[di][4 * u + 1] << 8) | ((uint32_t)dg[di][4 * u + 2] << 16) | ((uint32_t)dg[di][4 * u + 3] << 24);
+                        at8[(((size_t)w * kI8Steps + sidx) * 4 + di) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
                     }
                 }
+        // bt8[wave][lane]: lane (j, kq) holds rows 4*kq + 0..3 of every column; the digits' terms
+        // 128 * rowsum (weights 2^0..2^24, nothing at 2^32) combined like the kernel's accumulators
+        bt8.assign((size_t)4 * 64, make_uint4(0u, 0u, 0u, 0u));
+        for (int w = 0; w < 4; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                float bf[4];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r;
+                    float v = 0.0f;
+                    for (int di = 3; di >= 0; --di)
+                        v = std::fmaf(v, 256.0f, (float)(128 * rowsum[((size_t)w * 4 + di) * 16 + row]));
+                    bf[r] = v;
+                }
+                uint4 u;
+                std::memcpy(&u, bf, 16);
+                bt8[(size_t)w * 64 + lane] = u;
+            }
     }
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
-    if (e == hipSuccess && p->mfma_bf16) e = hipMalloc((void **)&p->d_atab16, at16.size() * sizeof(uint4));
-    if (e == hipSuccess && p->mfma_bf16) e = hipMemcpy(p->d_atab16, at16.data(), at16.size() * sizeof(uint4), hipMemcpyHostToDevice);
+    if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_atab8, at8.size() * sizeof(uint4));
+    if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_atab8, at8.data(), at8.size() * sizeof(uint4), hipMemcpyHostToDevice);
+    if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_btab8, bt8.size() * sizeof(uint4));
+    if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_btab8, bt8.data(), bt8.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess && p->mfma) e = hipMalloc((void **)&p->d_atab, at.size() * sizeof(float4));
     if (e == hipSuccess && p->mfma) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_gtab, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -1406,7 +1608,8 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (!p) return SDR_OK;
     if (p->d_gtab) (void)hipFree(p->d_gtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
-    if (p->d_atab16) (void)hipFree(p->d_atab16);
+    if (p->d_atab8) (void)hipFree(p->d_atab8);
+    if (p->d_btab8) (void)hipFree(p->d_btab8);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     delete p;
@@ -1439,7 +1642,7 @@ extern "C" int sdr_fir_plan_shape(const sdr_fir_plan *p, int *input, int *mode, 
 
 extern "C" int sdr_fir_plan_kernel(const sdr_fir_plan *p)
 {
-    return p ? (p->mfma_bf16 ? 5 : (p->mfma ? 4 : (p->planar ? 3 : (p->raw ? 1 : 2)))) : 0;
+    return p ? (p->mfma_i8 ? 5 : (p->mfma ? 4 : (p->planar ? 3 : (p->raw ? 1 : 2)))) : 0;
 }
 
 extern "C" int sdr_fir_execute_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, void *d_out,

@@ -176,7 +176,7 @@ def test_geometries_against_oracle(sdr, oracle, T, D):
     ran = 0
     for R in (1, 2, 4, 8):
         for NT in (64, 128, 256):
-            for pipe in (1, 2, 3, 4, 5):   # raw tile / persistent float tiles / planar float tile / MFMA f32 / MFMA split bf16
+            for pipe in (1, 2, 3, 4):   # raw tile / persistent float tiles / planar float tile / MFMA f32
                 try:
                     p_fm = sdr.FirPlan(h, D, mode=sdr.MODE_FM, outputs_per_lane=R, threads=NT,
                                        pipeline=pipe)
@@ -193,6 +193,18 @@ def test_geometries_against_oracle(sdr, oracle, T, D):
                 check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_IQ, outputs_per_lane=R, threads=NT,
                                          pipeline=pipe).execute_host(iq), y, tag)
     assert ran >= 3
+    # int8 matrix kernel: one geometry of its own
+    tag = f"T={T} D={D} pipe=5"
+    try:
+        p5 = sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5)
+    except sdr.SdrError as e:
+        assert e.status == sdr.capi.EINVAL and D >= 16    # two tile buffers of 16*D*31 samples exceed the LDS
+        return
+    check_fm(p5.execute_host(iq), fm, y, 1 / TWO_PI, tag)
+    check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_ENV, pipeline=5).execute_host(iq), env, tag)
+    check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_IQ, pipeline=5).execute_host(iq), y, tag)
+    with pytest.raises(sdr.SdrError):
+        sdr.FirPlan(h, D, mode=sdr.MODE_IQ, pipeline=5, threads=256)
 
 
 def test_float_inputs_and_mixer(sdr, oracle):
@@ -606,9 +618,9 @@ def test_time_shard_beyond_2_pow_32_samples(sdr, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,D", [(511, 10), (511, 15), (300, 7), (64, 10)])
-def test_split_bf16_matrix_path_full_range(sdr, oracle, T, D):
-    """pipeline 5 splits int16 samples into two exact bf16 halves and the taps into three bf16
-    pieces: the whole int16 range (incl. -32768 and 32767, far beyond Q11) and taps of mixed
+def test_byte_split_matrix_path_full_range(sdr, oracle, T, D):
+    """pipeline 5 feeds the int8 matrix pipe with the samples' two bytes and the taps' four base-256
+    digits: the whole int16 range (incl. -32768 and 32767, far beyond Q11) and taps of mixed
     magnitude must come out at float32 accuracy, edges (zero history, ragged end) included"""
     rng = np.random.default_rng(T + D)
     n = 150_001
@@ -624,5 +636,5 @@ def test_split_bf16_matrix_path_full_range(sdr, oracle, T, D):
         assert np.abs(got.astype(want.dtype) - want).max() <= 1e-5 * 16 * 0.5, (T, D, mode)
     fm = oracle.polar_discriminator(y, 1 / TWO_PI)
     got = sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5).execute_host(iq)
-    check_fm(got, fm, y, 1 / TWO_PI, f"bf16 T={T} D={D}")
-    assert sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5).info()["kernel"] == "mfma_bf16"
+    check_fm(got, fm, y, 1 / TWO_PI, f"i8 T={T} D={D}")
+    assert sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5).info()["kernel"] == "mfma_i8"

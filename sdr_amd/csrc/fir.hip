@@ -858,17 +858,15 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 // LDS buffer; waves 8-11 ("finishing waves", two outputs per lane) finish the previous tile (sum
 // of the four matrix waves' partial results, discriminator / envelope, stores):
 //   phase p:  matrix: k loop of tile p-1    | staging: tile p -> buffer p&1,   | finishing: tile p-2
-//             (buffer (p-1)&1)              |          request tile p+2        |   from part
-//             barrier A
-//             matrix: partial sums of tile p-1 -> part      | (the others wait)
-//             barrier B
-// `part` is read by the finishing waves before A and written by the matrix waves between A and B.
+//             (buffer (p-1)&1), partial     |          request tile p+2        |   from part[p&1]
+//             sums -> part[(p-1)&1]         |                                  |
+//             barrier
 //   A (taps):    lane (i = lane % 16, kq = lane / 16) holds digit d of H[i][64*ks + 16*kq + 0..15],
 //                H[i][k] = q[D*i + Tb - k] (the Toeplitz skew lives here, so sample reads stay aligned)
 //   B (samples): lane (j, kq) holds bytes 16*D*grp + 64*ks + 16*kq + 0..15 of plane (j & 1, hi | lo)
 //   C:           lane (j, kq) holds outputs 4*kq + 0..3 of group grp = 8*cb + j/2, component j & 1
 // (the order of the 64 k values inside a step only has to be the same in A and B).
-// LDS: 2 x [I hi | Q hi | I lo | Q lo] byte planes | part (4 waves x 4 blocks x 64 lanes x float4).
+// LDS: 2 x [I hi | Q hi | I lo | Q lo] byte planes | 2 x part (4 waves x 4 blocks x 64 lanes x float4).
 // ---------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kI8Steps = 3;        // k steps per matrix wave (12 steps of 64 = windows up to 768 samples)
@@ -892,6 +890,16 @@ __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgk
 // s_waitcnt vmcnt(0) before every load, which serialises the HBM round trips.  Only tiles that
 // touch an end of the stream (wave-uniform test) then repair the quads in registers: samples
 // outside the stream read as zero.
+// n-th tile of this workgroup.  A round is gridDim.x consecutive tiles; within a round XCD x (the
+// workgroups with blockIdx.x % 8 == x) takes the x-th contiguous eighth, so neighbouring tiles --
+// whose windows overlap by the filter length -- meet in one L2.
+__device__ __forceinline__ int i8_tile_index(int n)
+{
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int slot = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
+    return n * G + slot;
+}
+
 struct I8Tile {
     const uint32_t *base;   // sample 0 of the tile (W0); may point before the buffer: only clamped offsets are dereferenced
     int lo, hi;             // valid samples of the tile, tile-relative: [lo, hi)
@@ -972,8 +980,9 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     const int tid = threadIdx.x;
     const bool matrix = tid < 256;
     const int buf_bytes = 4 * plane_bytes;
-    f32x4 *part = (f32x4 *)(smem + 2 * buf_bytes);             // [wave][column block][lane]
-    const int n_t = (g.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // this workgroup's tiles
+    f32x4 *part = (f32x4 *)(smem + 2 * buf_bytes);             // [tile parity][wave][column block][lane]
+    // this workgroup's tiles: n_t rounds (the last one may be partial)
+    const int n_t = (g.total_tiles - i8_tile_index(0) + (int)gridDim.x - 1) / (int)gridDim.x;
 
     if (matrix) {
         const int wave = tid >> 6, lane = tid & 63;
@@ -1032,27 +1041,26 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xh, acc[3], 0, 0, 0);
                     }
                     if (s == NSTEPS - 1) {
-                        // sum of 2^(8w) * acc[w] in float32, top weight first (balanced digits: the top
-                        // term carries the value, the rest are corrections -- nothing cancels)
+                        // sum of 2^(8w) * acc[w]: weights 0|1 and 2|3 pair up exactly in int32 (|acc| <
+                        // 2^23), then float32 from the top (balanced digits: the top term carries the
+                        // value, the rest are corrections -- nothing cancels)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
+                            const int t01 = acc[1][r] * 256 + acc[0][r], t23 = acc[3][r] * 256 + acc[2][r];
                             float v = (float)acc[4][r];
-                            v = __fmaf_rn(v, 256.0f, (float)acc[3][r]);
-                            v = __fmaf_rn(v, 256.0f, (float)acc[2][r]);
-                            v = __fmaf_rn(v, 256.0f, (float)acc[1][r]);
-                            v = __fmaf_rn(v, 256.0f, (float)acc[0][r]);
+                            v = __fmaf_rn(v, 65536.0f, (float)t23);
+                            v = __fmaf_rn(v, 65536.0f, (float)t01);
                             res[cb][r] = v + bias[r];
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            lds_only_barrier();                                // A
             if (work) {
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) part[(wave * 4 + cb) * 64 + lane] = res[cb];
+                for (int cb = 0; cb < 4; ++cb) part[(((p - 1) & 1) * 16 + wave * 4 + cb) * 64 + lane] = res[cb];
             }
-            lds_only_barrier();                                // B
+            lds_only_barrier();
         }
     } else if (tid < 512) {
         // ================= staging waves: fetch, split, stage =================================
@@ -1067,7 +1075,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             // unconditional (past the end: the last tile again, unused): a skipped request would make
             // the registers conditionally defined and hipcc would copy them right after the loads
             n = n < n_t ? n : n_t - 1;
-            const I8Tile tl = i8_tile(g, in, blockIdx.x + n * gridDim.x);
+            const I8Tile tl = i8_tile(g, in, i8_tile_index(n));
 #pragma unroll
             for (int k = 0; k < kI8Pre; ++k)
 #pragma unroll
@@ -1076,7 +1084,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         auto phase = [&](int p, uint4 (&w)[kI8Pre][2]) {
             if (p < n_t && !(SDR_I8_ABL & 2)) {
                 unsigned char *buf = smem + (p & 1) * buf_bytes;
-                const I8Tile tl = i8_tile(g, in, blockIdx.x + p * gridDim.x);
+                const I8Tile tl = i8_tile(g, in, i8_tile_index(p));
                 auto put = [&](int oct, uint4 q0, uint4 q1) {
                     if (tl.edge) {                             // wave-uniform
                         q0 = i8_repair(tl, 2 * oct, g.s_gran, q0);
@@ -1098,8 +1106,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     put(oct, i8_fetch(tl, 2 * oct, g.s_gran), i8_fetch(tl, 2 * oct + 1, g.s_gran));
             }
             request(p + 2, w);
-            lds_only_barrier();                                // A
-            lds_only_barrier();                                // B
+            lds_only_barrier();
         };
         request(0, w0);
         request(1, w1);
@@ -1117,7 +1124,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         const float *pb = (const float *)(part + (o2 >> 7) * 64 + ((o2 & 15) >> 2) * 16 + 2 * ((o2 >> 4) & 7)) + (o2 & 3);
         for (int p = 0; p <= n_t + 1; ++p) {
             if (p >= 2 && !(SDR_I8_ABL & 4)) {
-                const int t = blockIdx.x + (p - 2) * gridDim.x;
+                const int t = i8_tile_index(p - 2);
                 const long long ch = t / g.tiles_per_ch;
                 const long long M0 = g.tile0 + (long long)(t - (int)ch * g.tiles_per_ch) * g.per_tile;
                 float2 v[2][4];                                // [component][wave]: outputs o0, o0+1
@@ -1126,8 +1133,8 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int wv = 0; wv < 4; ++wv) {
-                        v[c][wv] = *(const float2 *)(pa + (wv * 4 * 64 + c) * 4);
-                        z[c][wv] = pb[(wv * 4 * 64 + c) * 4];
+                        v[c][wv] = *(const float2 *)(pa + (((p & 1) * 16 + wv * 4) * 64 + c) * 4);
+                        z[c][wv] = pb[(((p & 1) * 16 + wv * 4) * 64 + c) * 4];
                     }
                 // one summation order for every output; then the power-of-two scale
                 float2 y[2], ynext;
@@ -1139,8 +1146,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                                     (((z[1][0] + z[1][1]) + z[1][2]) + z[1][3]) * yscale);
                 store_outputs<2>(g, outv, ch, M0 + 2LL * ft, y, ynext, M0 + g.per_tile);
             }
-            lds_only_barrier();                                // A
-            lds_only_barrier();                                // B
+            lds_only_barrier();
         }
     }
 }
@@ -1161,6 +1167,7 @@ struct sdr_fir_plan {
     uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave
     int plane_bytes = 0;
     float yscale = 1.f;         // its output scale 2^-(F+11)
+    sdr_fir_plan *tiny = nullptr;   // automatic choice only: the VALU plan that takes streams shorter than 4 samples
     double scale, mix_fr;
     int spg;                // samples per LDS granule: 4 (raw) / 2 (stream)
     int Tback, Lw4, ngran, q, pad, s_gran, a_gran, n_inst, lds_bytes;
@@ -1286,7 +1293,12 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.out_stride = out_stride;
     g.lo_valid = in_first > 0 ? in_first : 0;
     g.hi_valid = (in_first + n_resident < n_total) ? in_first + n_resident : n_total;
-    if (p->mfma_i8 && g.hi_valid - g.lo_valid < 4) { sdr::set_error("pipeline 5 needs at least 4 resident samples"); return SDR_EINVAL; }
+    if (p->mfma_i8 && g.hi_valid - g.lo_valid < 4) {
+        // its staging loads are 4 samples wide and clamped into the valid range
+        if (p->tiny) return launch(p->tiny, in, in_first, n_resident, n_total, out_begin, out_end, in_stride, n_ch, out, out_stride, st);
+        sdr::set_error("pipeline 5 needs at least 4 resident samples");
+        return SDR_EINVAL;
+    }
     g.tile0 = out_begin & ~3LL;
     g.out_begin = out_begin;
     g.out_end = out_end;
@@ -1388,14 +1400,21 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         best = gm; bestR = 2; bestNT = 256; best_raw = true;
         p->mfma = true;
     }
-    if (d->pipeline == 5) {
+    // Long filters (>= 32 MACs per input sample) go to the int8 matrix pipe when the tile fits: 2x the
+    // VALU kernels at 511 taps / 10 (tools/eval_mfma.py), exact integer accumulation.
+    const bool auto_i8 = d->pipeline == 0 && raw_possible && d->n_taps >= 32 * d->decim && !d->outputs_per_lane && !d->threads;
+    if (d->pipeline == 5 || auto_i8) {
+        bool fits = true;
         // byte-split Toeplitz GEMM: 512 outputs per tile, k steps of 64 dealt to 4 matrix waves
         if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 has one geometry (512 outputs per tile, 768 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
         Geometry gm{};
         gm.Tback = roundup(p->T - 1, 4);
         const int W = gm.Tback + 15 * p->D + 1;
         const int nks = (W + 63) / 64;
-        if (nks > 4 * kI8Steps) { sdr::set_error("pipeline 5: window of %d samples exceeds %d (decim=%d taps=%d)", W, 64 * 4 * kI8Steps, p->D, p->T); delete p; return SDR_EINVAL; }
+        if (nks > 4 * kI8Steps) {
+            if (!auto_i8) { sdr::set_error("pipeline 5: window of %d samples exceeds %d (decim=%d taps=%d)", W, 64 * 4 * kI8Steps, p->D, p->T); delete p; return SDR_EINVAL; }
+            fits = false;
+        }
         gm.ngran = nks;                                     // k steps of 64
         const long long s_tile = (long long)p->D * 16 * 31 + 64LL * 4 * ((nks + 3) / 4);   // last group's base + every wave's steps
         gm.s_gran = (int)(s_tile / 4);                      // quads of samples staged
@@ -1427,10 +1446,15 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             }
             p->plane_bytes = base + best_skew;
         }
-        gm.lds_bytes = 2 * 4 * p->plane_bytes + 16384;        // two tile buffers + the partial sums
-        if (gm.lds_bytes > 160 * 1024) { sdr::set_error("pipeline 5: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); delete p; return SDR_EINVAL; }
-        best = gm; bestR = 2; bestNT = 256; best_raw = true;   // 256 finishing lanes, two outputs each
-        p->mfma_i8 = true;
+        gm.lds_bytes = 2 * 4 * p->plane_bytes + 2 * 16384;    // two tile buffers + two sets of partial sums
+        if (gm.lds_bytes > 160 * 1024) {
+            if (!auto_i8) { sdr::set_error("pipeline 5: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); delete p; return SDR_EINVAL; }
+            fits = false;
+        }
+        if (fits) {
+            best = gm; bestR = 2; bestNT = 256; best_raw = true;   // 256 finishing lanes, two outputs each
+            p->mfma_i8 = true;
+        }
     }
     if (!bestR && raw_possible && d->pipeline != 2) {
         const int pref_small[4] = {4, 2, 1, 8}, pref_large[4] = {2, 4, 1, 8};
@@ -1577,9 +1601,11 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 float bf[4];
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * (lane >> 4) + r;
+                    const int *rs = &rowsum[(size_t)w * 4 * 16 + row];        // [digit * 16]
+                    const int t01 = 128 * rs[16] * 256 + 128 * rs[0], t23 = 128 * rs[48] * 256 + 128 * rs[32];
                     float v = 0.0f;
-                    for (int di = 3; di >= 0; --di)
-                        v = std::fmaf(v, 256.0f, (float)(128 * rowsum[((size_t)w * 4 + di) * 16 + row]));
+                    v = std::fmaf(v, 65536.0f, (float)t23);
+                    v = std::fmaf(v, 65536.0f, (float)t01);
                     bf[r] = v;
                 }
                 uint4 u;
@@ -1599,6 +1625,11 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         sdr_fir_plan_destroy(p);
         return sdr::hip_fail(e, "plan upload");
     }
+    if (p->mfma_i8 && d->pipeline == 0) {
+        sdr_fir_desc d2 = *d;
+        d2.pipeline = 1;                                       // raw tile
+        if (sdr_fir_plan_create(&d2, &p->tiny) != SDR_OK) p->tiny = nullptr;
+    }
     *out = p;
     return SDR_OK;
 }
@@ -1608,6 +1639,7 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (!p) return SDR_OK;
     if (p->d_gtab) (void)hipFree(p->d_gtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
+    if (p->tiny) (void)sdr_fir_plan_destroy(p->tiny);
     if (p->d_atab8) (void)hipFree(p->d_atab8);
     if (p->d_btab8) (void)hipFree(p->d_btab8);
     if (p->d_in) (void)hipFree(p->d_in);

@@ -638,3 +638,19 @@ def test_byte_split_matrix_path_full_range(sdr, oracle, T, D):
     got = sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5).execute_host(iq)
     check_fm(got, fm, y, 1 / TWO_PI, f"i8 T={T} D={D}")
     assert sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5).info()["kernel"] == "mfma_i8"
+
+
+@pytest.mark.gpu
+def test_long_filter_automatic_choice_and_tiny_streams(sdr, oracle):
+    """long filters (T >= 32*D) go to the int8 matrix kernel on their own; streams shorter than its
+    4-sample staging loads are handed to the VALU plan it keeps for that"""
+    h = oracle.create_fir_filter(101, 0.3, "hann")
+    p = sdr.FirPlan(h, 3, mode=sdr.MODE_IQ)
+    assert p.info()["kernel"] == "mfma_i8"
+    assert sdr.FirPlan(h, 10, mode=sdr.MODE_IQ).info()["kernel"] != "mfma_i8"     # 101 < 32 * 10
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 3, 4, 5, 11, 4097):
+        iq = rng.integers(-2048, 2048, 2 * n, dtype=np.int16)
+        want = oracle.fir_decimate(oracle.unpack_scale_i16(iq), 3, h)
+        got = p.execute_host(iq)
+        check_linear(got, want, f"n={n}")

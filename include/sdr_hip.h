@@ -103,7 +103,7 @@ typedef struct sdr_fir_desc {
     int mode;           /* enum sdr_mode */
     int decim;          /* D >= 1 */
     int n_taps;         /* T >= 1; NO "T % D == 0" restriction */
-    const double *taps; /* host, T doubles (rounded to float32 on upload) */
+    const double *taps; /* host, T doubles (rounded to float32 on upload; pipeline 5: to 31-bit fixed point) */
     double scale;       /* FM: discriminator scale, e.g. 1/(2*pi) (bladerf_apt_demod.cpp:560) */
     double mix_fr;      /* != 0: multiply x[n] by exp(+j*2*pi*mix_fr*n) before the FIR
                            (frequency_shift, bladerf_apt_demod.cpp:476-495; sign as
@@ -118,7 +118,11 @@ typedef struct sdr_fir_desc {
                              3 = int16 converted once while staging into two float planes in LDS,
                              one tile per workgroup (int16 input without mixer only);
                              4 = the same float planes, window walk as a Toeplitz GEMM on the
-                             matrix cores in float32 (long filters; int16 without mixer only) */
+                             matrix cores in float32 (long filters; int16 without mixer only);
+                             5 = Toeplitz GEMM on the int8 matrix pipe: samples as their two
+                             bytes, taps as four base-256 digits, exact int32 accumulation
+                             (windows T + 15*D up to 768 samples; int16 without mixer only;
+                             leave outputs_per_lane and threads 0).  Automatic for T >= 32*D. */
 } sdr_fir_desc;
 
 /* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument
@@ -131,7 +135,8 @@ size_t sdr_fir_out_count(const sdr_fir_plan *plan, size_t n_in);
 /* what the plan chose: outputs per lane, threads per workgroup, LDS bytes per workgroup */
 int sdr_fir_plan_info(const sdr_fir_plan *plan, int *outputs_per_lane, int *threads,
                       int *lds_bytes);
-/* which kernel the plan runs: 1 = raw-tile, 2 = streaming, 3 = planar, 4 = MFMA (see `pipeline`) */
+/* which kernel the plan runs: 1 = raw-tile, 2 = streaming, 3 = planar, 4 = MFMA float32,
+ * 5 = MFMA int8 (see `pipeline`) */
 int sdr_fir_plan_kernel(const sdr_fir_plan *plan);
 
 /* One block from zero pre-history, host buffers.  Replaces, fused in one pass,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long-filter evaluation (BASELINE config 5): the same 511-tap / decimate-by-10 FIR through the
-raw-tile (VALU, converts per read), planar (VALU, converts once) and MFMA Toeplitz kernels, warm,
-interleaved so that all three see the same clocks.  Run under rocprofv3 --kernel-trace --stats for
+raw-tile (VALU, converts per read), planar (VALU, converts once), float32 MFMA Toeplitz and int8
+matrix-pipe Toeplitz kernels, warm, interleaved so that all see the same clocks.  Run under rocprofv3 --kernel-trace --stats for
 the per-kernel summary kept in profiles/."""
 import json
 import os
@@ -12,13 +12,13 @@ import sdr_amd  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 sdr_amd.init(0)
-n, T, D = 1 << 26, 511, 10
+n, T, D = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 26), 511, 10
 h = sdr_amd.create_fir_filter(T, 20800 / 62400.0 / 5, "hann")
 d_in = sdr_amd.DevBuf(n * 4 + 64)
 sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=624e3, ftone=2400.0, dev=17000.0, amp=1800.0, noise_lsb=4, seed=5)
 d_out = sdr_amd.DevBuf(n // D * 8 + 64)
 plans = {name: sdr_amd.FirPlan(h, D, mode=sdr_amd.MODE_FM, pipeline=p)
-         for name, p in (("raw_tile", 1), ("planar", 3), ("mfma", 4))}
+         for name, p in (("raw_tile", 1), ("planar", 3), ("mfma_f32", 4), ("mfma_i8", 5))}
 m = 1 << 20
 iq = d_in.to_numpy(np.int16, 2 * m)
 want = O.chain_i16(iq, D, h, O.MODE_FM)
@@ -34,4 +34,5 @@ for _ in range(4):
 flops = 4.0 * T / D * n
 for name, ms in best.items():
     print(json.dumps({"kernel": name, "taps": T, "decim": D, "samples": n, "ms": round(ms, 4),
-                      "useful_fp32_TFLOPs": round(flops / ms / 1e9, 1), "info": plans[name].info()}), flush=True)
+                      "useful_TFLOPs_equiv": round(flops / ms / 1e9, 1),
+                      "input_GBps": round(4.0 * n / ms / 1e6, 1), "info": plans[name].info()}), flush=True)

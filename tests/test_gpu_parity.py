@@ -654,3 +654,67 @@ def test_long_filter_automatic_choice_and_tiny_streams(sdr, oracle):
         want = oracle.fir_decimate(oracle.unpack_scale_i16(iq), 3, h)
         got = p.execute_host(iq)
         check_linear(got, want, f"n={n}")
+
+
+@pytest.mark.gpu
+def test_int8_matrix_kernel_shards_and_channels(sdr, oracle):
+    """the int8 matrix kernel behind the other entry points: time shards with their history halo
+    (tiles that start before / end after the resident window), channel-major batches (tiles of
+    several channels in one persistent grid) and the streaming hand-off"""
+    D, T = 10, 511
+    h = oracle.create_fir_filter(T, 0.07, "hann")
+    rng = np.random.default_rng(9)
+    # ---- time shards -------------------------------------------------------------------------
+    n = 400_011
+    iq = oracle.synth_fm_i16(n, fs=624e3, ftone=2400.0, dev=17000.0, amp=1800.0)
+    iq = (iq + rng.integers(-6, 7, iq.size)).astype(np.int16)
+    for mode, omode in ((sdr.MODE_FM, oracle.MODE_FM), (sdr.MODE_ENV, oracle.MODE_ENV)):
+        plan = sdr.FirPlan(h, D, mode=mode)
+        assert plan.info()["kernel"] == "mfma_i8"
+        want = oracle.chain_i16(iq, D, h, omode)
+        cnt = want.size
+        parts = []
+        for gidx in range(3):
+            ob, oe = cnt * gidx // 3, cnt * (gidx + 1) // 3
+            lo = max(0, ob * D - (T - 1))
+            hi = min(n, (oe + 1) * D + 1)
+            d_blk = sdr.DevBuf.from_numpy(iq[2 * lo: 2 * hi])
+            d_out = sdr.DevBuf((oe - ob) * 4)
+            plan.execute_range_dev(d_blk, lo, hi - lo, n, ob, oe, d_out)
+            sdr.sync()
+            parts.append(d_out.to_numpy(np.float32, oe - ob))
+        got = np.concatenate(parts).astype(np.float64)
+        settle = T // D + 2
+        assert np.abs(got - want)[settle:].max() <= 1e-5 * 0.5, mode
+    # ---- channel-major batch -------------------------------------------------------------------
+    n_ch, nc = 9, 30_007
+    stride_in = nc + 40
+    buf = np.zeros(2 * stride_in * n_ch, np.int16)
+    for c in range(n_ch):
+        buf[2 * c * stride_in: 2 * (c * stride_in + nc)] = oracle.synth_fm_i16(
+            nc, fs=624e3, ftone=900.0 + 333.0 * c, dev=9000.0, amp=1500.0)
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_ENV)
+    cnt = plan.out_count(nc)
+    stride_out = cnt + 5
+    d_in = sdr.DevBuf.from_numpy(buf)
+    d_out = sdr.DevBuf(stride_out * n_ch * 4)
+    plan.execute_batched_dev(d_in, nc, stride_in, n_ch, d_out, stride_out)
+    sdr.sync()
+    out = d_out.to_numpy(np.float32, stride_out * n_ch)
+    for c in range(n_ch):
+        want = oracle.chain_i16(buf[2 * c * stride_in: 2 * (c * stride_in + nc)], D, h, oracle.MODE_ENV)
+        check_linear(out[c * stride_out: c * stride_out + cnt], want, f"channel {c}")
+    # ---- streaming hand-off: history carried across blocks --------------------------------------
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_ENV)
+    blk = 20_000
+    st = sdr.FirStream(plan, blk)
+    outs = []
+    for b in range(6):
+        st.push(iq[2 * b * blk: 2 * (b + 1) * blk])
+        if b:
+            outs.append(st.pop())
+    outs.append(st.pop())
+    got = np.concatenate(outs)
+    want = oracle.chain_i16(iq[: 2 * 6 * blk], D, h, oracle.MODE_ENV)
+    check_linear(got, want[: got.size], "stream")
+    assert got.size == want.size

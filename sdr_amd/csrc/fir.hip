@@ -679,39 +679,75 @@ __device__ __forceinline__ void pwalk_p(const FirGeom &g, const float4 *re4, con
 constexpr int kPlanarSlots = 8;     // granules one lane stages per round of loads
 
 // Stage one tile as two float planes: every lane fetches its granules (4 int16 pairs each), converts
-// them once and writes I and Q to re4[] / im4[].
+// them once and writes I and Q to re4[] / im4[].  The loads are branch-free: each granule comes from
+// an address clamped into the stream's valid samples, and only tiles that touch an end of the
+// stream (wave-uniform test) repair their granules in registers afterwards.  (Loads on two paths
+// into the same registers make hipcc wait for vmcnt(0) before every load, one HBM round trip each.)
 __device__ __forceinline__ void stage_planar(const FirGeom &g, const uint32_t *__restrict__ src,
                                              long long W0, float4 *re4, float4 *im4, int tid, int NT)
 {
-    const bool interior = (W0 >= g.lo_valid) && (W0 + 4LL * g.s_gran <= g.hi_valid);
+    const long long n = 4LL * g.s_gran;
+    long long lo_l = g.lo_valid - W0, hi_l = g.hi_valid - W0;
+    lo_l = lo_l < 0 ? 0 : (lo_l > n ? n : lo_l);
+    hi_l = hi_l > n ? n : (hi_l < lo_l ? lo_l : hi_l);
+    const int lo = (int)lo_l, hi = (int)hi_l;                // valid samples of the tile: [lo, hi)
+    const uint32_t *base = src + W0;                         // only clamped offsets are dereferenced
+    if (hi - lo < 4) {
+        // fewer than four valid samples under the tile: no 16-byte load fits, fetch sample by sample
+        for (int a = tid; a < g.a_gran; a += NT) {
+            int sg = sample_granule(g, a);
+            sg = sg < g.s_gran ? sg : 0;
+            float fi[4], fq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int si = 4 * sg + u;
+                const uint32_t e = (si >= lo && si < hi) ? base[si] : 0u;
+                fi[u] = lo16(e);
+                fq[u] = hi16(e);
+            }
+            re4[a] = make_float4(fi[0], fi[1], fi[2], fi[3]);
+            im4[a] = make_float4(fq[0], fq[1], fq[2], fq[3]);
+        }
+        return;
+    }
+    const bool edge = lo > 0 || hi < (int)n;
+    const int top = hi - 4;
     for (int k0 = 0; k0 < g.n_inst; k0 += kPlanarSlots) {
         uint4 w[kPlanarSlots];
+        int rel[kPlanarSlots];
         // all loads of the round first, unconditionally (slots past the tile repeat its last
-        // round-robin row: a branch per load would serialise the HBM round trips)
+        // round-robin row)
 #pragma unroll
         for (int k = 0; k < kPlanarSlots; ++k) {
             const int kk = (k0 + k < g.n_inst) ? k0 + k : g.n_inst - 1;
             int sg = sample_granule(g, kk * NT + tid);
             sg = sg < g.s_gran ? sg : 0;
-            const long long s = W0 + 4LL * sg;
-            if (interior) {
-                w[k] = *(const uint4 *)(src + s);
-            } else {
-                uint32_t e[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const long long si = s + u;
-                    e[u] = (si >= g.lo_valid && si < g.hi_valid) ? src[si] : 0u;
-                }
-                w[k] = make_uint4(e[0], e[1], e[2], e[3]);
-            }
+            rel[k] = 4 * sg;
+            const int at = rel[k] < lo ? lo : (rel[k] > top ? top : rel[k]);
+            w[k] = *(const uint4 *)(base + at);
         }
 #pragma unroll
         for (int k = 0; k < kPlanarSlots; ++k) {
             const int a = (k0 + k) * NT + tid;
             if (k0 + k < g.n_inst && a < g.a_gran) {
-                re4[a] = make_float4(lo16(w[k].x), lo16(w[k].y), lo16(w[k].z), lo16(w[k].w));
-                im4[a] = make_float4(hi16(w[k].x), hi16(w[k].y), hi16(w[k].z), hi16(w[k].w));
+                uint32_t e[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+                if (edge) {                                  // wave-uniform
+                    const int at = rel[k] < lo ? lo : (rel[k] > top ? top : rel[k]);
+                    uint32_t o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int si = rel[k] + u, idx = si - at;
+                        uint32_t v = e[0];
+                        v = idx == 1 ? e[1] : v;
+                        v = idx == 2 ? e[2] : v;
+                        v = idx == 3 ? e[3] : v;
+                        o[u] = (si >= lo && si < hi && idx >= 0 && idx < 4) ? v : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = o[u];
+                }
+                re4[a] = make_float4(lo16(e[0]), lo16(e[1]), lo16(e[2]), lo16(e[3]));
+                im4[a] = make_float4(hi16(e[0]), hi16(e[1]), hi16(e[2]), hi16(e[3]));
             }
         }
     }

@@ -122,7 +122,8 @@ typedef struct sdr_fir_desc {
                              5 = Toeplitz GEMM on the int8 matrix pipe: samples as their two
                              bytes, taps as four base-256 digits, exact int32 accumulation
                              (windows T + 15*D up to 768 samples; int16 without mixer only;
-                             leave outputs_per_lane and threads 0).  Automatic for T >= 32*D. */
+                             leave outputs_per_lane and threads 0).  Chosen automatically where a
+                             measured cost model (tiles vs taps per sample) puts it ahead. */
 } sdr_fir_desc;
 
 /* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument

@@ -1436,9 +1436,20 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         best = gm; bestR = 2; bestNT = 256; best_raw = true;
         p->mfma = true;
     }
-    // Long filters (>= 32 MACs per input sample) go to the int8 matrix pipe when the tile fits: 2x the
-    // VALU kernels at 511 taps / 10 (tools/eval_mfma.py), exact integer accumulation.
-    const bool auto_i8 = d->pipeline == 0 && raw_possible && d->n_taps >= 32 * d->decim && !d->outputs_per_lane && !d->threads;
+    // Automatic choice between the vector-unit kernels and the int8 matrix kernel, from a sweep of
+    // ten shapes on MI355X (T = 64..511, D = 4..20), in ms per 2^28 samples:
+    //   vector unit:  max(0.256 [HBM], 0.17 + 0.0125 * T/D)
+    //   matrix pipe:  max(0.29 [HBM, persistent tiles], tiles per CU * (1.2 | 1.35 | 1.7 us for 1 | 2 | 3 k steps per wave))
+    // The matrix kernel's time follows the number of 512-output tiles, not the filter length.
+    bool auto_i8 = false;
+    if (d->pipeline == 0 && raw_possible && !d->outputs_per_lane && !d->threads) {
+        const double t_valu = std::fmax(0.256, 0.17 + 0.0125 * (double)d->n_taps / (double)d->decim);
+        const int Wn = roundup(d->n_taps - 1, 4) + 15 * d->decim + 1;
+        const int steps = ((Wn + 63) / 64 + 3) / 4;
+        const double per_tile_us = steps <= 1 ? 1.2 : (steps == 2 ? 1.35 : 1.7);
+        const double t_i8 = std::fmax(0.29, (2048.0 / (double)d->decim) * per_tile_us * 1e-3);
+        auto_i8 = t_i8 < 0.9 * t_valu;
+    }
     if (d->pipeline == 5 || auto_i8) {
         bool fits = true;
         // byte-split Toeplitz GEMM: 512 outputs per tile, k steps of 64 dealt to 4 matrix waves

@@ -642,12 +642,15 @@ def test_byte_split_matrix_path_full_range(sdr, oracle, T, D):
 
 @pytest.mark.gpu
 def test_long_filter_automatic_choice_and_tiny_streams(sdr, oracle):
-    """long filters (T >= 32*D) go to the int8 matrix kernel on their own; streams shorter than its
-    4-sample staging loads are handed to the VALU plan it keeps for that"""
-    h = oracle.create_fir_filter(101, 0.3, "hann")
+    """filters with enough work per 512-output tile go to the int8 matrix kernel on their own; streams
+    shorter than its 4-sample staging loads are handed to the VALU plan it keeps for that"""
+    h = oracle.create_fir_filter(201, 0.3, "hann")
     p = sdr.FirPlan(h, 3, mode=sdr.MODE_IQ)
     assert p.info()["kernel"] == "mfma_i8"
-    assert sdr.FirPlan(h, 10, mode=sdr.MODE_IQ).info()["kernel"] != "mfma_i8"     # 101 < 32 * 10
+    for T, D, want_i8 in ((64, 10, False), (101, 5, False), (101, 20, False), (128, 8, True), (200, 10, True),
+                          (195, 15, True), (511, 10, True), (511, 15, True)):
+        k = sdr.FirPlan(oracle.create_fir_filter(T, 0.5 / D, "hann"), D, mode=sdr.MODE_FM).info()["kernel"]
+        assert (k == "mfma_i8") == want_i8, (T, D, k)
     rng = np.random.default_rng(5)
     for n in (0, 1, 2, 3, 4, 5, 11, 4097):
         iq = rng.integers(-2048, 2048, 2 * n, dtype=np.int16)

@@ -18,7 +18,9 @@
 // lays out as a zero-padded table gtab[j][r]; the table index is wave-uniform, so taps arrive
 // through scalar loads and cost no LDS or VALU work.
 //
-// Two kernels share that scheme:
+// Three vector-unit kernels share that scheme (fir_planar_kernel: float planes converted once, see
+// its header); long filters run as a Toeplitz GEMM on the int8 matrix cores instead
+// (fir_mfma_i8_kernel, chosen by sdr_fir_plan_create from a measured cost model):
 //   fir_raw_kernel     (automatic choice for int16 input without mixer) keeps the RAW int16 pairs
 //       in LDS, filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), and converts
 //       after each LDS read.  Half the LDS footprint: 7 workgroups per CU on the headline shape.

@@ -21,7 +21,7 @@ import csv,glob,collections
 for f in sorted(glob.glob("$OUT/*/*/*_counter_collection.csv")):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if ("fir_" in r["Kernel_Name"] or "fft_" in r["Kernel_Name"]) and "synth" not in r["Kernel_Name"]:
+        if ("fir_" in r["Kernel_Name"] or "fft" in r["Kernel_Name"]) and "synth" not in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in agg.items(): print(f"{k:28s} {sum(v)/len(v):16.0f}  (n={len(v)})")
 PY

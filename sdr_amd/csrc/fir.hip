@@ -888,13 +888,15 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 // before that last step, and zero samples give exact zeros.
 // Staging is eight byte permutes per four samples -- no conversions.
 //
-// 768 lanes in two roles.  Waves 0-3 ("matrix waves", one per SIMD) only run k loops: the k range
+// 768 lanes in three roles.  Waves 0-3 ("matrix waves", one per SIMD) only run k loops: the k range
 // (window offsets, steps of 64) is dealt to them round-robin, wave w owns steps w, w+4, w+8 for all
-// four column blocks (16 columns = 8 groups of 16 outputs x {I, Q}), so its share of the tap matrix
-// (3 steps x 4 digits x 16 B per lane = 48 VGPRs) is loaded once per kernel.  Waves 4-7 ("staging
-// waves") fetch the raw samples two tiles ahead, split them and stage the next tile into the other
-// LDS buffer; waves 8-11 ("finishing waves", two outputs per lane) finish the previous tile (sum
-// of the four matrix waves' partial results, discriminator / envelope, stores):
+// NCB column blocks of the tile (a block = 16 columns = 8 groups of 16 outputs x {I, Q}; NCB = 8,
+// a tile of 1024 outputs, when the LDS holds it, else 4), so its share of the tap matrix (3 steps
+// x 4 digits x 16 B per lane = 48 VGPRs) is loaded once per kernel.  Waves 4-7 ("staging waves")
+// fetch the raw samples ahead (two 512-output tiles or one 1024-output tile), split them and stage
+// the next tile into the other LDS buffer; waves 8-11 ("finishing waves", NCB/2 outputs per lane)
+// finish the previous tile (sum of the four matrix waves' partial results, discriminator /
+// envelope, stores):
 //   phase p:  matrix: k loop of tile p-1    | staging: tile p -> buffer p&1,   | finishing: tile p-2
 //             (buffer (p-1)&1), partial     |          request tile p+2        |   from part[p&1]
 //             sums -> part[(p-1)&1]         |                                  |
@@ -904,11 +906,11 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 //   B (samples): lane (j, kq) holds bytes 16*D*grp + 64*ks + 16*kq + 0..15 of plane (j & 1, hi | lo)
 //   C:           lane (j, kq) holds outputs 4*kq + 0..3 of group grp = 8*cb + j/2, component j & 1
 // (the order of the 64 k values inside a step only has to be the same in A and B).
-// LDS: 2 x [I hi | Q hi | I lo | Q lo] byte planes | 2 x part (4 waves x 4 blocks x 64 lanes x float4).
+// LDS: 2 x [I hi | Q hi | I lo | Q lo] byte planes | 2 x part (4 waves x NCB blocks x 64 lanes x float4).
 // ---------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kI8Steps = 3;        // k steps per matrix wave (12 steps of 64 = windows up to 768 samples)
-constexpr int kI8Pre = 4;          // octets (8 samples) a staging lane fetches ahead: 4 x 256 x 8 samples per tile
+// octets (8 samples) a staging lane fetches ahead per tile: 4 (6 for the 1024-output tile) x 256 x 8 samples
 
 #ifdef SDR_I8_ABLATE
 #define SDR_I8_ABL SDR_I8_ABLATE
@@ -1008,7 +1010,7 @@ __device__ __forceinline__ void i8_split4(uint4 w, uint32_t &il, uint32_t &ih, u
 // NSTEPS = k steps per matrix wave = ceil(steps in the window / 4).  Steps past the window carry
 // zero taps (the staged tile covers 4*NSTEPS steps, so their sample reads stay inside it); only the
 // last step is skipped by the waves that do not own a real one.
-template <int NSTEPS>
+template <int NSTEPS, int NCB>
 __global__ void __launch_bounds__(768, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
@@ -1042,14 +1044,11 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         const int cb_bytes = 16 * g.D * 8;                     // between column blocks
         for (int p = 0; p <= n_t + 1; ++p) {
             const bool work = p >= 1 && p <= n_t;
-            f32x4 res[4];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) res[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (work && !(SDR_I8_ABL & 1)) {
                 const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs;
                 // units of (column block, step), samples requested one unit ahead
                 i32x4 b[2][2];                                 // [buffer][hi, lo]
-                constexpr int UNITS = 4 * NSTEPS;
+                constexpr int UNITS = NCB * NSTEPS;
                 b[0][0] = as_i32x4(*(const uint4 *)bbase);
                 b[0][1] = as_i32x4(*(const uint4 *)(bbase + 2 * plane_bytes));
                 i32x4 acc[5];
@@ -1082,21 +1081,20 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         // sum of 2^(8w) * acc[w]: weights 0|1 and 2|3 pair up exactly in int32 (|acc| <
                         // 2^23), then float32 from the top (balanced digits: the top term carries the
                         // value, the rest are corrections -- nothing cancels)
+                        f32x4 rv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int t01 = acc[1][r] * 256 + acc[0][r], t23 = acc[3][r] * 256 + acc[2][r];
                             float v = (float)acc[4][r];
                             v = __fmaf_rn(v, 65536.0f, (float)t23);
                             v = __fmaf_rn(v, 65536.0f, (float)t01);
-                            res[cb][r] = v + bias[r];
+                            rv[r] = v + bias[r];
                         }
+                        // this tile's set of partial sums is not read before the next phase
+                        part[((((p - 1) & 1) * 4 + wave) * NCB + cb) * 64 + lane] = rv;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            if (work) {
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) part[(((p - 1) & 1) * 16 + wave * 4 + cb) * 64 + lane] = res[cb];
             }
             lds_only_barrier();
         }
@@ -1108,6 +1106,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // raw samples of two tiles travel at any time: set p&1 holds tile p until it is staged in
         // phase p and is then refilled with tile p+2 (one tile ahead did not cover the HBM latency).
         // These waves issue no stores, so waiting for a set never waits for anything else.
+        constexpr int kI8Pre = NCB > 4 ? 6 : 4;
         uint4 w0[kI8Pre][2], w1[kI8Pre][2];
         auto request = [&](int n, uint4 (&w)[kI8Pre][2]) {     // n-th tile of this workgroup
             // unconditional (past the end: the last tile again, unused): a skipped request would make
@@ -1143,21 +1142,30 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 for (int oct = 256 * kI8Pre + st; oct < n_oct; oct += 256)     // very wide tiles only
                     put(oct, i8_fetch(tl, 2 * oct, g.s_gran), i8_fetch(tl, 2 * oct + 1, g.s_gran));
             }
-            request(p + 2, w);
+            request(p + (NCB > 4 ? 1 : 2), w);
             lds_only_barrier();
         };
-        request(0, w0);
-        request(1, w1);
-        for (int p = 0; p <= n_t + 1; p += 2) {
-            phase(p, w0);
-            if (p + 1 <= n_t + 1) phase(p + 1, w1);
+        if constexpr (NCB > 4) {
+            // 1024-output tiles take twice as long: one tile ahead gives the same lead, in half the registers
+            request(0, w0);
+            for (int p = 0; p <= n_t + 1; ++p) phase(p, w0);
+        } else {
+            request(0, w0);
+            request(1, w1);
+            for (int p = 0; p <= n_t + 1; p += 2) {
+                phase(p, w0);
+                if (p + 1 <= n_t + 1) phase(p + 1, w1);
+            }
         }
     } else {
         // ================= finishing waves: partial sums -> epilogue -> stores ==================
-        const int ft = tid - 512;                              // 0..255: outputs 2*ft, 2*ft+1 of the tile
-        // where outputs 2*ft, 2*ft+1 (one float2) and, for the discriminator, 2*ft+2 sit in `part`:
-        // output o = 16*grp + i is element i&3 of lane (i>>2)*16 + 2*(grp&7) + component, block grp>>3
-        const int o0 = 2 * ft, o2 = o0 + 2 < 512 ? o0 + 2 : 511;
+        const int ft = tid - 512;                              // 0..255: outputs R*ft .. R*ft+R-1 of the tile
+        constexpr int R = NCB / 2;                             // 2 (512-output tile) or 4 (1024)
+        constexpr int TILE = 128 * NCB;
+        // where those outputs (one float2 / float4: R divides 4) and, for the discriminator, their
+        // successor sit in `part`: output o = 16*grp + i is element i&3 of lane
+        // (i>>2)*16 + 2*(grp&7) + component, column block grp>>3
+        const int o0 = R * ft, o2 = o0 + R < TILE ? o0 + R : TILE - 1;
         const float *pa = (const float *)(part + (o0 >> 7) * 64 + ((o0 & 15) >> 2) * 16 + 2 * ((o0 >> 4) & 7)) + (o0 & 3);
         const float *pb = (const float *)(part + (o2 >> 7) * 64 + ((o2 & 15) >> 2) * 16 + 2 * ((o2 >> 4) & 7)) + (o2 & 3);
         for (int p = 0; p <= n_t + 1; ++p) {
@@ -1165,24 +1173,31 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 const int t = i8_tile_index(p - 2);
                 const long long ch = t / g.tiles_per_ch;
                 const long long M0 = g.tile0 + (long long)(t - (int)ch * g.tiles_per_ch) * g.per_tile;
-                float2 v[2][4];                                // [component][wave]: outputs o0, o0+1
-                float z[2][4];                                 //                     output o2
+                float v[2][4][R];                              // [component][wave][output]
+                float z[2][4];                                 // the successor
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int wv = 0; wv < 4; ++wv) {
-                        v[c][wv] = *(const float2 *)(pa + (((p & 1) * 16 + wv * 4) * 64 + c) * 4);
-                        z[c][wv] = pb[(((p & 1) * 16 + wv * 4) * 64 + c) * 4];
+                        const int off = ((((p & 1) * 4 + wv) * NCB) * 64 + c) * 4;
+                        if constexpr (R == 4) {
+                            const float4 q = *(const float4 *)(pa + off);
+                            v[c][wv][0] = q.x; v[c][wv][1] = q.y; v[c][wv][2] = q.z; v[c][wv][3] = q.w;
+                        } else {
+                            const float2 q = *(const float2 *)(pa + off);
+                            v[c][wv][0] = q.x; v[c][wv][1] = q.y;
+                        }
+                        z[c][wv] = pb[off];
                     }
                 // one summation order for every output; then the power-of-two scale
-                float2 y[2], ynext;
-                y[0] = make_float2((((v[0][0].x + v[0][1].x) + v[0][2].x) + v[0][3].x) * yscale,
-                                   (((v[1][0].x + v[1][1].x) + v[1][2].x) + v[1][3].x) * yscale);
-                y[1] = make_float2((((v[0][0].y + v[0][1].y) + v[0][2].y) + v[0][3].y) * yscale,
-                                   (((v[1][0].y + v[1][1].y) + v[1][2].y) + v[1][3].y) * yscale);
+                float2 y[R], ynext;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    y[r] = make_float2((((v[0][0][r] + v[0][1][r]) + v[0][2][r]) + v[0][3][r]) * yscale,
+                                       (((v[1][0][r] + v[1][1][r]) + v[1][2][r]) + v[1][3][r]) * yscale);
                 ynext = make_float2((((z[0][0] + z[0][1]) + z[0][2]) + z[0][3]) * yscale,
                                     (((z[1][0] + z[1][1]) + z[1][2]) + z[1][3]) * yscale);
-                store_outputs<2>(g, outv, ch, M0 + 2LL * ft, y, ynext, M0 + g.per_tile);
+                store_outputs<R>(g, outv, ch, M0 + (long long)R * ft, y, ynext, M0 + g.per_tile);
             }
             lds_only_barrier();
         }
@@ -1259,19 +1274,19 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
 {
     if (p->mfma_i8) {
         const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
-#define SDR_I8(NS)                                                                               \
+#define SDR_I8(NS, CB)                                                                           \
     do {                                                                                         \
         if (p->lds_bytes > 64 * 1024)                                                            \
-            (void)hipFuncSetAttribute((const void *)fir_mfma_i8_kernel<NS>,                      \
+            (void)hipFuncSetAttribute((const void *)fir_mfma_i8_kernel<NS, CB>,                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes); \
-        fir_mfma_i8_kernel<NS><<<nb, 768, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
-                                                              p->plane_bytes, p->yscale);                \
+        fir_mfma_i8_kernel<NS, CB><<<nb, 768, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
+                                                                  p->plane_bytes, p->yscale);                \
     } while (0)
-        switch ((p->ngran + 3) / 4) {
-        case 1: SDR_I8(1); break;
-        case 2: SDR_I8(2); break;
-        default: SDR_I8(3); break;
-        }
+        const int ns = (p->ngran + 3) / 4;
+        if (p->R == 4) { if (ns <= 1) SDR_I8(1, 8); else if (ns == 2) SDR_I8(2, 8); else SDR_I8(3, 8); }
+        else if (ns <= 1) SDR_I8(1, 4);
+        else if (ns == 2) SDR_I8(2, 4);
+        else SDR_I8(3, 4);
 #undef SDR_I8
         return hipGetLastError();
     }
@@ -1441,21 +1456,26 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     // Automatic choice between the vector-unit kernels and the int8 matrix kernel, from a sweep of
     // ten shapes on MI355X (T = 64..511, D = 4..20), in ms per 2^28 samples:
     //   vector unit:  max(0.256 [HBM], 0.17 + 0.0125 * T/D)
-    //   matrix pipe:  max(0.29 [HBM, persistent tiles], tiles per CU * (1.2 | 1.35 | 1.7 us for 1 | 2 | 3 k steps per wave))
-    // The matrix kernel's time follows the number of 512-output tiles, not the filter length.
+    //   matrix pipe:  max(0.26 [HBM], tiles per CU * time per tile); a tile is 1024 outputs (1.85 | 2.1 |
+    //                 3.2 us for 1 | 2 | 3 k steps per matrix wave) when the LDS holds it, else 512
+    //                 (1.2 | 1.35 | 1.7 us)
+    // The matrix kernel's time follows the number of tiles, not the filter length.
     bool auto_i8 = false;
     if (d->pipeline == 0 && raw_possible && !d->outputs_per_lane && !d->threads) {
         const double t_valu = std::fmax(0.256, 0.17 + 0.0125 * (double)d->n_taps / (double)d->decim);
         const int Wn = roundup(d->n_taps - 1, 4) + 15 * d->decim + 1;
         const int steps = ((Wn + 63) / 64 + 3) / 4;
-        const double per_tile_us = steps <= 1 ? 1.2 : (steps == 2 ? 1.35 : 1.7);
-        const double t_i8 = std::fmax(0.29, (2048.0 / (double)d->decim) * per_tile_us * 1e-3);
+        const bool big = 2 * 4 * (roundup(16 * d->decim * 63 + 256 * steps, 256) + 240) + 65536 <= 160 * 1024;
+        const double per_tile_us = big ? (steps <= 1 ? 1.85 : (steps == 2 ? 2.1 : 3.2))
+                                       : (steps <= 1 ? 1.2 : (steps == 2 ? 1.35 : 1.7));
+        const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
+        const double t_i8 = std::fmax(0.26, tiles_per_cu * per_tile_us * 1e-3);
         auto_i8 = t_i8 < 0.9 * t_valu;
     }
     if (d->pipeline == 5 || auto_i8) {
         bool fits = true;
-        // byte-split Toeplitz GEMM: 512 outputs per tile, k steps of 64 dealt to 4 matrix waves
-        if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 has one geometry (512 outputs per tile, 768 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
+        // byte-split Toeplitz GEMM: 1024 or 512 outputs per tile, k steps of 64 dealt to 4 matrix waves
+        if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 chooses its own geometry (768 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
         Geometry gm{};
         gm.Tback = roundup(p->T - 1, 4);
         const int W = gm.Tback + 15 * p->D + 1;
@@ -1465,14 +1485,14 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             fits = false;
         }
         gm.ngran = nks;                                     // k steps of 64
-        const long long s_tile = (long long)p->D * 16 * 31 + 64LL * 4 * ((nks + 3) / 4);   // last group's base + every wave's steps
-        gm.s_gran = (int)(s_tile / 4);                      // quads of samples staged
-        gm.a_gran = gm.s_gran;
-        gm.n_inst = (gm.a_gran + 255) / 256;
-        gm.q = 1; gm.pad = 0;
-        // byte planes, 1 B per sample; the offset between the I and Q planes is chosen so that the
-        // 16-lane groups of the matrix waves' ds_read_b128 (MI355X_MICROARCH.md, LDS) meet no bank twice
-        {
+        const int ns = (nks + 3) / 4;                       // per matrix wave
+        // tile of 1024 outputs (8 column blocks, 4 outputs per finishing lane) when the LDS holds it,
+        // else 512 outputs
+        int ncb = 0;
+        for (int cand = 8; cand >= 4 && !ncb; cand -= 4) {
+            const long long s_tile = (long long)p->D * 16 * (8 * cand - 1) + 64LL * 4 * ns;   // last group's base + every wave's steps
+            // byte planes, 1 B per sample; the offset between the I and Q planes is chosen so that the
+            // 16-lane groups of the matrix waves' ds_read_b128 (MI355X_MICROARCH.md, LDS) meet no bank twice
             static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                            {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                            {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
@@ -1493,15 +1513,23 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 }
                 if (cost < best_cost) { best_cost = cost; best_skew = skew; }
             }
-            p->plane_bytes = base + best_skew;
+            const int plane = base + best_skew;
+            const int lds = 2 * 4 * plane + 2 * 4 * cand * 1024;   // two tile buffers + two sets of partial sums
+            if (lds > 160 * 1024 && cand > 4) continue;
+            ncb = cand;
+            p->plane_bytes = plane;
+            gm.lds_bytes = lds;
+            gm.s_gran = (int)(s_tile / 4);                  // quads of samples staged
         }
-        gm.lds_bytes = 2 * 4 * p->plane_bytes + 2 * 16384;    // two tile buffers + two sets of partial sums
+        gm.a_gran = gm.s_gran;
+        gm.n_inst = (gm.a_gran + 255) / 256;
+        gm.q = 1; gm.pad = 0;
         if (gm.lds_bytes > 160 * 1024) {
             if (!auto_i8) { sdr::set_error("pipeline 5: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); delete p; return SDR_EINVAL; }
             fits = false;
         }
         if (fits) {
-            best = gm; bestR = 2; bestNT = 256; best_raw = true;   // 256 finishing lanes, two outputs each
+            best = gm; bestR = ncb / 2; bestNT = 256; best_raw = true;   // 256 finishing lanes, two or four outputs each
             p->mfma_i8 = true;
         }
     }

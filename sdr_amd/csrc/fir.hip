@@ -888,13 +888,14 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 // before that last step, and zero samples give exact zeros.
 // Staging is eight byte permutes per four samples -- no conversions.
 //
-// 768 lanes in three roles.  Waves 0-3 ("matrix waves", one per SIMD) only run k loops: the k range
+// 1024 lanes in three roles.  Waves 0-7 ("matrix waves", two per SIMD, each pair sharing its k steps
+// and splitting the column blocks) only run k loops: the k range
 // (window offsets, steps of 64) is dealt to them round-robin, wave w owns steps w, w+4, w+8 for all
 // NCB column blocks of the tile (a block = 16 columns = 8 groups of 16 outputs x {I, Q}; NCB = 8,
 // a tile of 1024 outputs, when the LDS holds it, else 4), so its share of the tap matrix (3 steps
-// x 4 digits x 16 B per lane = 48 VGPRs) is loaded once per kernel.  Waves 4-7 ("staging waves")
+// x 4 digits x 16 B per lane = 48 VGPRs) is loaded once per kernel.  Waves 8-11 ("staging waves")
 // fetch the raw samples ahead (two 512-output tiles or one 1024-output tile), split them and stage
-// the next tile into the other LDS buffer; waves 8-11 ("finishing waves", NCB/2 outputs per lane)
+// the next tile into the other LDS buffer; waves 12-15 ("finishing waves", NCB/2 outputs per lane)
 // finish the previous tile (sum of the four matrix waves' partial results, discriminator /
 // envelope, stores):
 //   phase p:  matrix: k loop of tile p-1    | staging: tile p -> buffer p&1,   | finishing: tile p-2
@@ -1011,21 +1012,24 @@ __device__ __forceinline__ void i8_split4(uint4 w, uint32_t &il, uint32_t &ih, u
 // zero taps (the staged tile covers 4*NSTEPS steps, so their sample reads stay inside it); only the
 // last step is skipped by the waves that do not own a real one.
 template <int NSTEPS, int NCB>
-__global__ void __launch_bounds__(768, 1)
+__global__ void __launch_bounds__(1024, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
                    const int plane_bytes, const float yscale)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const bool matrix = tid < 256;
+    const bool matrix = tid < 512;
     const int buf_bytes = 4 * plane_bytes;
     f32x4 *part = (f32x4 *)(smem + 2 * buf_bytes);             // [tile parity][wave][column block][lane]
     // this workgroup's tiles: n_t rounds (the last one may be partial)
     const int n_t = (g.total_tiles - i8_tile_index(0) + (int)gridDim.x - 1) / (int)gridDim.x;
 
     if (matrix) {
-        const int wave = tid >> 6, lane = tid & 63;
+        // eight matrix waves, two per SIMD: wave (tid / 64) % 4 owns k steps as described above, and
+        // the two waves with the same steps take one half of the tile's column blocks each
+        const int wave = (tid >> 6) & 3, lane = tid & 63;
+        const int cb0 = (tid >> 8) * (NCB / 2);
         const int j = lane & 15, kq = lane >> 4;
         const bool last_real = wave + 4 * (NSTEPS - 1) < g.ngran;   // does this wave own a real last step?
         // 128 * (sum of this wave's digits of each output row), combined over the digits exactly as the
@@ -1045,10 +1049,10 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         for (int p = 0; p <= n_t + 1; ++p) {
             const bool work = p >= 1 && p <= n_t;
             if (work && !(SDR_I8_ABL & 1)) {
-                const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs;
+                const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs + cb0 * cb_bytes;
                 // units of (column block, step), samples requested one unit ahead
                 i32x4 b[2][2];                                 // [buffer][hi, lo]
-                constexpr int UNITS = NCB * NSTEPS;
+                constexpr int UNITS = (NCB / 2) * NSTEPS;
                 b[0][0] = as_i32x4(*(const uint4 *)bbase);
                 b[0][1] = as_i32x4(*(const uint4 *)(bbase + 2 * plane_bytes));
                 i32x4 acc[5];
@@ -1091,16 +1095,16 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                             rv[r] = v + bias[r];
                         }
                         // this tile's set of partial sums is not read before the next phase
-                        part[((((p - 1) & 1) * 4 + wave) * NCB + cb) * 64 + lane] = rv;
+                        part[((((p - 1) & 1) * 4 + wave) * NCB + cb0 + cb) * 64 + lane] = rv;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             lds_only_barrier();
         }
-    } else if (tid < 512) {
+    } else if (tid < 768) {
         // ================= staging waves: fetch, split, stage =================================
-        const int st = tid - 256;                              // 0..255
+        const int st = tid - 512;                              // 0..255
         const int cI = g.swap_iq ? 1 : 0;                      // Q-first input swaps the component planes
         const int n_oct = (g.s_gran + 1) / 2;                  // octets per tile
         // raw samples of two tiles travel at any time: set p&1 holds tile p until it is staged in
@@ -1159,7 +1163,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         }
     } else {
         // ================= finishing waves: partial sums -> epilogue -> stores ==================
-        const int ft = tid - 512;                              // 0..255: outputs R*ft .. R*ft+R-1 of the tile
+        const int ft = tid - 768;                              // 0..255: outputs R*ft .. R*ft+R-1 of the tile
         constexpr int R = NCB / 2;                             // 2 (512-output tile) or 4 (1024)
         constexpr int TILE = 128 * NCB;
         // where those outputs (one float2 / float4: R divides 4) and, for the discriminator, their
@@ -1279,7 +1283,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         if (p->lds_bytes > 64 * 1024)                                                            \
             (void)hipFuncSetAttribute((const void *)fir_mfma_i8_kernel<NS, CB>,                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes); \
-        fir_mfma_i8_kernel<NS, CB><<<nb, 768, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
+        fir_mfma_i8_kernel<NS, CB><<<nb, 1024, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale);                \
     } while (0)
         const int ns = (p->ngran + 3) / 4;
@@ -1475,7 +1479,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->pipeline == 5 || auto_i8) {
         bool fits = true;
         // byte-split Toeplitz GEMM: 1024 or 512 outputs per tile, k steps of 64 dealt to 4 matrix waves
-        if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 chooses its own geometry (768 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
+        if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 chooses its own geometry (1024 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
         Geometry gm{};
         gm.Tback = roundup(p->T - 1, 4);
         const int W = gm.Tback + 15 * p->D + 1;
@@ -1599,7 +1603,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         if (per_cu > wave_cap) per_cu = wave_cap;
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
-        if (p->mfma_i8) per_cu = 1;                           // 768 lanes, one matrix wave per SIMD
+        if (p->mfma_i8) per_cu = 1;                           // 1024 lanes, two matrix waves per SIMD
         p->stream_blocks = ncu * per_cu;
     }
 

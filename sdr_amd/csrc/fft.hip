@@ -387,6 +387,103 @@ fft_db_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fft4096_pair_kernel: the 4096-point, hop-2048 case with TWO frames per lane.  fft_db_kernel is
+// bound by neither HBM nor a saturated unit but by dependent chains: three waves per SIMD leave
+// the vector unit ~60 % busy.  Here a lane transforms frames f and f+1 together --
+// two independent instruction streams in one wave, one set of window values and twiddles (all in
+// registers, no LDS tables), three half frames of raw samples of which the middle one serves both
+// frames -- and a workgroup needs one barrier sequence per PAIR.  232 VGPRs -> two waves per SIMD,
+// i.e. four frames in flight per SIMD instead of three, at half the barriers per frame.
+// LDS: two frame images (70 KB), two workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+fft4096_pair_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
+                    const cf *__restrict__ tw, float *__restrict__ out, const FftGeom g)
+{
+    constexpr int N = 4096, TPF = 256;
+    constexpr int FR_LDS = N + N / 16;     // padded complex values per frame image
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    cf *img0 = (cf *)dyn_smem, *img1 = img0 + FR_LDS;
+    const int tl = threadIdx.x;
+
+    cf wv[8];                              // window values, two per register pair
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) wv[t >> 1] = cf{win[tl + t * TPF], win[tl + (t + 1) * TPF]};
+    cf w2[15], w3[15];
+    pass_twiddles<N, 16>(w2, tl, 16, tw);
+    pass_twiddles<N, 16>(w3, tl, 256, tw);
+    const int base2 = (tl >> 4) * 256 + (tl & 15);
+
+    const long long f0 = (long long)blockIdx.x * g.chunk;          // chunk is even
+    long long f_end = f0 + g.chunk;
+    if (f_end > g.frames) f_end = g.frames;
+    const long long half_last = g.frames;                           // last half frame of the stream
+    auto fetch = [&](long long h, uint32_t (&r)[8]) {               // half frame h of the stream
+        h = h < half_last ? h : half_last;
+        const uint32_t *src = iq + h * g.hop;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) r[t] = src[tl + t * TPF];
+    };
+    auto load_frame = [&](cf (&x)[16], const uint32_t (&lo)[8], const uint32_t (&hi)[8]) {
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            const uint32_t r0 = t < 8 ? lo[t] : hi[t - 8], r1 = t < 8 ? lo[t + 1] : hi[t - 7];
+            const cf a = {(float)(short)(r0 & 0xffffu), (float)((int)r0 >> 16)};
+            const cf b = {(float)(short)(r1 & 0xffffu), (float)((int)r1 >> 16)};
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(x[t]) : "v"(a), "v"(wv[t >> 1]));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(x[t + 1]) : "v"(b), "v"(wv[t >> 1]));
+        }
+    };
+
+    // half frames 2i, 2i+1, 2i+2 of this workgroup's run for pair i; the next pair's two new ones in flight
+    uint32_t ha[8], hb[8], hc[8], na[8], nb[8];
+    fetch(f0, ha);
+    fetch(f0 + 1, hb);
+    fetch(f0 + 2, hc);
+    for (long long fa = f0; fa < f0 + g.chunk; fa += 2) {
+        float *row_a = fa < f_end ? out + fa * N : g.dummy;
+        float *row_b = fa + 1 < f_end ? out + (fa + 1) * N : g.dummy;
+        fetch(fa + 3, na);
+        fetch(fa + 4, nb);
+        // ---- pass 1 of both frames --------------------------------------------------------------
+        {
+            cf x0[16], x1[16];
+            load_frame(x0, ha, hb);
+            load_frame(x1, hb, hc);
+            dft<16>(x0);
+            dft<16>(x1);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { img0[pidx(tl * 16 + t)] = x0[t]; img1[pidx(tl * 16 + t)] = x1[t]; }
+        }
+        lds_barrier();
+        // ---- pass 2 ------------------------------------------------------------------------------
+        {
+            cf y0[16], y1[16];
+            pass_load<N, 16>(y0, img0, tl, w2);
+            pass_load<N, 16>(y1, img1, tl, w2);
+            lds_barrier();                 // every lane has gathered its inputs
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { img0[pidx(base2 + t * 16)] = y0[t]; img1[pidx(base2 + t * 16)] = y1[t]; }
+        }
+        lds_barrier();
+        // ---- pass 3, |X|^2 -> dB, fft-shifted rows ---------------------------------------------------
+        {
+            cf z0[16], z1[16];
+            pass_load<N, 16>(z0, img0, tl, w3);
+            pass_load<N, 16>(z1, img1, tl, w3);
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+                emit_db2<N>(row_a, tl + t * 256, tl + (t + 1) * 256, z0[t], z0[t + 1]);
+                emit_db2<N>(row_b, tl + t * 256, tl + (t + 1) * 256, z1[t], z1[t + 1]);
+            }
+        }
+        lds_barrier();                     // the images are free for the next pair
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { ha[t] = hc[t]; hb[t] = na[t]; hc[t] = nb[t]; }
+    }
+}
+
 }  // namespace
 
 struct sdr_fft_plan {
@@ -429,6 +526,21 @@ int launch_fft(sdr_fft_plan *p, const int16_t *d_iq, long long n_in, float *d_ou
         if (half) fft_db_kernel<N, R2, R3, true><<<grid, 256, 0, st>>>(in, p->d_win, (const cf *)p->d_tw, d_out, g); \
         else fft_db_kernel<N, R2, R3, false><<<grid, 256, 0, st>>>(in, p->d_win, (const cf *)p->d_tw, d_out, g);     \
     } while (0)
+    if (p->nfft == 4096 && half && frames >= 4LL * p->n_cu) {
+        // two frames per lane, two 256-lane workgroups per CU
+        FftGeom gp = g;
+        const long long wgs = 2LL * p->n_cu;
+        gp.chunk = (frames + wgs - 1) / wgs;
+        gp.chunk += gp.chunk & 1;
+        const unsigned nb = (unsigned)((frames + gp.chunk - 1) / gp.chunk);
+        const size_t lds = 2 * (size_t)(4096 + 256) * sizeof(float) * 2;
+        hipError_t ea = hipFuncSetAttribute((const void *)fft4096_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return sdr::hip_fail(ea, "fft kernel attribute");
+        fft4096_pair_kernel<<<nb, 256, lds, st>>>(in, p->d_win, (const cf *)p->d_tw, d_out, gp);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return sdr::hip_fail(e2, "fft kernel launch");
+        return SDR_OK;
+    }
     switch (p->nfft) {
     case 4096: SDR_FFT(4096, 16, 16); break;
     case 2048: SDR_FFT(2048, 16, 8); break;

@@ -5,7 +5,7 @@ sdr_amd.init(0)
 n = 1 << 26
 d_in = sdr_amd.DevBuf(n * 4 + 64)
 sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=61.44e6, ftone=250e3, dev=2.0e6, amp=1200.0, noise_lsb=64, seed=3)
-for nfft in (64, 256, 1024, 2048, 4096):
+for nfft in (64, 128, 256, 512, 1024, 2048, 4096):
     plan = sdr_amd.FftPlan(nfft, nfft // 2, sdr_amd.window("blackman", nfft))
     frames = plan.frame_count(n)
     d_out = sdr_amd.DevBuf(frames * nfft * 4)

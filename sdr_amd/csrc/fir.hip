@@ -1417,11 +1417,10 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     (void)hipGetDevice(&p->device);
     const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0);
     if ((d->pipeline == 1 || d->pipeline >= 3) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3, 4 and 5 need int16 input without mixer"); return SDR_EINVAL; }
-    // Long filters (>= 32 MACs per input sample) are bound by VALU issue and, sustained, by the
-    // power the conversions burn: the planar kernel converts once and runs T = 511 / D = 10 27 %
-    // faster when the chip is warm (0.230 vs 0.292 ms per 2^26 samples); short filters are bound
-    // by the HBM stream and want the raw tile's seven workgroups per CU.
-    const bool planar = (d->pipeline == 3) || (d->pipeline == 0 && raw_possible && d->n_taps >= 32 * d->decim);
+    // The planar kernel (float planes, convert once) is an explicit choice only: beyond the int8
+    // matrix kernel's window it is 8-12 % ahead of the raw tile at D = 8 and 10 but 1.4-1.8x behind
+    // at D = 16 and 20 (T = 640..2047, tools/sweep_shapes.py), so the automatic choice there is the raw tile.
+    const bool planar = (d->pipeline == 3);
 
     // ---- choose kernel, outputs per lane (R) and workgroup size (NT) ------------------------
     // Raw-tile / planar kernels (int16, no mixer), from geometry sweeps on MI355X

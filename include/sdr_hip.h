@@ -177,7 +177,9 @@ int sdr_fir_execute_batched_dev(sdr_fir_plan *plan, const void *d_in, size_t n_i
  * -> 20*log10(shift(abs(X), N/2)); plus the window multiply and hop of BASELINE config 4.
  * Frame f covers samples [f*hop, f*hop+nfft); out[f*nfft + i] = 10*log10(|X_f[(i+nfft/2) %
  * nfft]|^2) with X = (1/nfft) * DFT(w .* x/2048).  No log floor (exact zeros give -inf, as in
- * the reference).  nfft: a power of two, 64 .. 4096.  window may be NULL (rectangular). */
+ * the reference).  nfft: a power of two, 64 .. 1048576 (up to 4096 the frame is transformed in
+ * registers; longer frames, like the reference's one 131072-sample block, go through multi-pass
+ * kernels with plan-owned scratch).  window may be NULL (rectangular). */
 int sdr_fft_plan_create(int nfft, int hop, const double *window, sdr_fft_plan **plan);
 int sdr_fft_plan_destroy(sdr_fft_plan *plan);
 size_t sdr_fft_frame_count(const sdr_fft_plan *plan, size_t n_in);

@@ -495,6 +495,58 @@ fft4096_pair_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ w
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Frames longer than 4096 points (the reference transforms one 131072-sample capture block,
+// bladerf_main_v1.cpp:139): Stockham autosort passes of radix 4 (one radix-2 pass at the end when
+// log2 N is odd) through two complex scratch arrays in HBM.  The first pass reads the int16 samples
+// and applies the window (which carries 2^-11 / N), the last one writes the fft-shifted dB row.
+// Twiddles come from sincospif of an exact dyadic fraction.  One lane per butterfly, grid.y = frame.
+// This path is for drop-in completeness (a capture block is ~2 ms of signal), not for the
+// waterfall benchmark, whose frames fit the register kernels above.
+// ---------------------------------------------------------------------------------------------
+template <int R, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256)
+fft_big_pass_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ win,
+                    const cf *__restrict__ src, cf *__restrict__ dst, float *__restrict__ out,
+                    int n, int ns, long long hop, long long frame0)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;            // butterfly index, 0 .. n/R - 1
+    if (j >= n / R) return;
+    const long long f = blockIdx.y;                          // frame within this launch
+    const int k = j & (ns - 1);
+    cf x[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int idx = j + t * (n / R);
+        if constexpr (FIRST) {
+            const uint32_t w = iq[(frame0 + f) * hop + idx];
+            const float wv = win[idx];
+            x[t] = cf{(float)(short)(w & 0xffffu) * wv, (float)((int)w >> 16) * wv};
+        } else {
+            x[t] = src[f * n + idx];
+        }
+    }
+#pragma unroll
+    for (int t = 1; t < R; ++t) {
+        // exp(-2*pi*i * t*k / (R*ns)): t*k < n <= 2^20 and R*ns is a power of two, so the argument is exact
+        float sn, cs;
+        sincospif(-2.0f * (float)(t * k) / (float)(R * ns), &sn, &cs);
+        x[t] = cf{x[t].x * cs - x[t].y * sn, x[t].x * sn + x[t].y * cs};
+    }
+    dft<R>(x);
+    const int o = (j - k) * R + k;                           // (j / ns) * ns * R + k
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int bin = o + t * ns;
+        if constexpr (LAST) {
+            const float p = __fmaf_rn(x[t].x, x[t].x, x[t].y * x[t].y);
+            out[(frame0 + f) * n + ((bin + n / 2) & (n - 1))] = 3.01029995663981195f * __log2f(p);
+        } else {
+            dst[f * n + bin] = x[t];
+        }
+    }
+}
+
 }  // namespace
 
 struct sdr_fft_plan {
@@ -505,6 +557,9 @@ struct sdr_fft_plan {
     float *d_dummy = nullptr;
     void *d_in = nullptr, *d_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
+    // frames longer than 4096 points: two complex scratch arrays, grown on demand
+    cf *d_scr[2] = {nullptr, nullptr};
+    size_t cap_scr = 0;             // complex values per array
 };
 
 namespace {
@@ -515,11 +570,54 @@ long long frame_count(const sdr_fft_plan *p, long long n)
     return (n - p->nfft) / p->hop + 1;
 }
 
+int launch_fft_big(sdr_fft_plan *p, const int16_t *d_iq, float *d_out, long long frames, hipStream_t st)
+{
+    const int n = p->nfft;
+    // frames per launch: scratch of at most 2 x 256 MB
+    long long per = (long long)(1 << 25) / n;
+    if (per < 1) per = 1;
+    if (per > frames) per = frames;
+    if (per > 65535) per = 65535;
+    const size_t need = (size_t)per * n;
+    if (need > p->cap_scr) {
+        for (int i = 0; i < 2; ++i) { if (p->d_scr[i]) (void)hipFree(p->d_scr[i]); p->d_scr[i] = nullptr; }
+        p->cap_scr = 0;
+        SDR_HIP(hipMalloc((void **)&p->d_scr[0], need * sizeof(cf)));
+        SDR_HIP(hipMalloc((void **)&p->d_scr[1], need * sizeof(cf)));
+        p->cap_scr = need;
+    }
+    const uint32_t *in = (const uint32_t *)d_iq;
+    int log2n = 0;
+    while ((1 << log2n) < n) ++log2n;
+    const int n4 = log2n / 2, n2 = log2n & 1;                // radix-4 passes, then one radix-2 pass
+    for (long long f0 = 0; f0 < frames; f0 += per) {
+        const unsigned nf = (unsigned)(frames - f0 < per ? frames - f0 : per);
+        int ns = 1, cur = 0;
+        for (int ps = 0; ps < n4 + n2; ++ps) {
+            const bool first = ps == 0, last = ps == n4 + n2 - 1;
+            const int R = ps < n4 ? 4 : 2;
+            const dim3 grid((unsigned)((n / R + 255) / 256), nf);
+            const cf *src = p->d_scr[cur];
+            cf *dst = p->d_scr[cur ^ 1];
+#define SDR_BIG(RR, FI, LA) fft_big_pass_kernel<RR, FI, LA><<<grid, 256, 0, st>>>(in, p->d_win, src, dst, d_out, n, ns, (long long)p->hop, f0)
+            if (R == 4) { if (first) SDR_BIG(4, true, false); else if (last) SDR_BIG(4, false, true); else SDR_BIG(4, false, false); }
+            else { if (last) SDR_BIG(2, false, true); else SDR_BIG(2, false, false); }
+#undef SDR_BIG
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return sdr::hip_fail(e, "fft pass launch");
+            ns *= R;
+            cur ^= 1;
+        }
+    }
+    return SDR_OK;
+}
+
 int launch_fft(sdr_fft_plan *p, const int16_t *d_iq, long long n_in, float *d_out,
                long long frames, hipStream_t st)
 {
     if (frames == 0) return SDR_OK;
     if (((uintptr_t)d_iq) & 3 || ((uintptr_t)d_out) & 3) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
+    if (p->nfft > 4096) return launch_fft_big(p, d_iq, d_out, frames, st);
     FftGeom g;
     g.n_in = n_in; g.frames = frames; g.hop = p->hop; g.dummy = p->d_dummy;
     const int fpb = 256 / (p->nfft / 16);
@@ -574,7 +672,7 @@ extern "C" int sdr_fft_plan_create(int nfft, int hop, const double *window, sdr_
 {
     if (!out) { sdr::set_error("null argument"); return SDR_EINVAL; }
     *out = nullptr;
-    if (nfft < 64 || nfft > 4096 || (nfft & (nfft - 1))) { sdr::set_error("nfft must be a power of two in 64..4096"); return SDR_EINVAL; }
+    if (nfft < 64 || nfft > (1 << 20) || (nfft & (nfft - 1))) { sdr::set_error("nfft must be a power of two in 64..1048576"); return SDR_EINVAL; }
     if (hop <= 0) { sdr::set_error("hop must be positive"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
@@ -611,6 +709,7 @@ extern "C" int sdr_fft_plan_destroy(sdr_fft_plan *p)
     if (p->d_win) (void)hipFree(p->d_win);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_dummy) (void)hipFree(p->d_dummy);
+    for (int i = 0; i < 2; ++i) if (p->d_scr[i]) (void)hipFree(p->d_scr[i]);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     delete p;

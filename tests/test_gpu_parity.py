@@ -721,3 +721,33 @@ def test_int8_matrix_kernel_shards_and_channels(sdr, oracle):
     want = oracle.chain_i16(iq[: 2 * 6 * blk], D, h, oracle.MODE_ENV)
     check_linear(got, want[: got.size], "stream")
     assert got.size == want.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nfft,hop", [(8192, 4096), (16384, 16384), (131072, 131072), (131072, 50_000)])
+def test_fft_long_frames(sdr, oracle, nfft, hop):
+    """a10 at the reference's own size: one 131072-sample capture block per transform
+    (bladerf_main_v1.cpp:139, no window, no overlap), plus other long frames with window / overlap;
+    the multi-pass path against the oracle's float64 FFT."""
+    rng = np.random.default_rng(nfft + hop)
+    frames = 3
+    n = (frames - 1) * hop + nfft + 17
+    t = np.arange(n)
+    ph = 2 * np.pi * (0.0913 * t + 3e-8 * t * t)
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = (1400 * np.cos(ph) + 300 * np.cos(0.7 * t) + rng.integers(-150, 151, n)).astype(np.int16)
+    iq[1::2] = (1400 * np.sin(ph) + rng.integers(-150, 151, n)).astype(np.int16)
+    w = None if hop == nfft == 131072 else oracle.window("blackman", nfft)
+    plan = sdr.FftPlan(nfft, hop, w)
+    assert plan.frame_count(n) == frames
+    got = plan.execute_host(iq).astype(np.float64)
+    assert got.shape == (frames, nfft) and np.isfinite(got).all()
+    want_db, want_lin = oracle.fft_power_db_i16(iq, nfft, hop, w, linear=True)
+    for f in range(frames):
+        lin = 10.0 ** (got[f] / 10.0)
+        peak = want_lin[f].max()
+        assert np.abs(lin - want_lin[f]).max() <= 1e-5 * peak, (nfft, hop, f)
+        strong = want_lin[f] > peak * 1e-5
+        assert np.abs(got[f] - want_db[f])[strong].max() <= 1e-3, (nfft, hop, f)
+    with pytest.raises(sdr.SdrError):
+        sdr.FftPlan(1 << 21, 1 << 21)

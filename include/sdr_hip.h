@@ -21,6 +21,12 @@
  *     (NULL = the default stream) and only enqueue work.
  *   - there is NO CPU fallback: without a gfx950 device sdr_init() and every plan call fail
  *     with SDR_ENODEV.
+ *   - threads and devices: a plan lives on the device that was current when it was created and
+ *     every execute call checks that the calling thread's current device is that one
+ *     (SDR_EINVAL otherwise).  Plans are immutable after creation except for the staging /
+ *     scratch buffers of the *_host entry points and of FFT frames longer than 4096 points:
+ *     those calls are one at a time per plan; *_dev calls of one plan may be enqueued on several
+ *     streams.  The last-error text is per thread.
  */
 #ifndef SDR_HIP_H_
 #define SDR_HIP_H_
@@ -231,7 +237,8 @@ int sdr_frequency_shift_dev(const float *d_in, int is_complex, size_t n, uint64_
  * out[i] = in[idx[i]] for elements of elem_dwords 32-bit words.  decimate_vec
  * (bladerf_apt_demod.cpp:374-401; cv_decimate, opencv_complex_functions.h:22-61) is this gather
  * with the reference's index sequence floor(0), floor(rate), floor(rate+rate), ... which the
- * C++ shim builds on the host exactly as the reference accumulates it. */
+ * C++ shim builds on the host exactly as the reference accumulates it.  An index >= n_in writes a
+ * zero element (never a read outside d_in). */
 int sdr_gather_dev(const void *d_in, int elem_dwords, size_t n_in, const uint64_t *d_idx,
                    size_t n_idx, void *d_out, void *stream);
 

@@ -327,6 +327,11 @@ def frequency_shift_dev(d_in, is_complex, n, n0, fr, d_out, stream=None):
                                         C.c_void_p(stream or 0)))
 
 
+def gather_dev(d_in, elem_dwords, n_in, d_idx, n_idx, d_out, stream=None):
+    check(lib().sdr_gather_dev(_vp(d_in), C.c_int(elem_dwords), C.c_size_t(n_in), _vp(d_idx),
+                               C.c_size_t(n_idx), _vp(d_out), C.c_void_p(stream or 0)))
+
+
 def synth_fm_i16_dev(d_iq, n, n0=0, fs=1.0e6, ftone=1000.0, dev=5000.0, amp=2000.0, noise_lsb=0,
                      seed=1, stream=None):
     check(lib().sdr_synth_fm_i16_dev(_vp(d_iq), C.c_size_t(n), C.c_uint64(n0), C.c_double(fs),

@@ -552,6 +552,8 @@ fft_big_pass_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ w
 struct sdr_fft_plan {
     int nfft, hop;
     int n_cu = 256;
+    int device = 0;
+    bool lds_opt_in = false;        // fft4096_pair_kernel's dynamic LDS limit has been raised
     float *d_win = nullptr;
     float2 *d_tw = nullptr;
     float *d_dummy = nullptr;
@@ -617,6 +619,7 @@ int launch_fft(sdr_fft_plan *p, const int16_t *d_iq, long long n_in, float *d_ou
 {
     if (frames == 0) return SDR_OK;
     if (((uintptr_t)d_iq) & 3 || ((uintptr_t)d_out) & 3) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
+    if (int rc = sdr::same_device(p->device)) return rc;
     if (p->nfft > 4096) return launch_fft_big(p, d_iq, d_out, frames, st);
     FftGeom g;
     g.n_in = n_in; g.frames = frames; g.hop = p->hop; g.dummy = p->d_dummy;
@@ -643,8 +646,11 @@ int launch_fft(sdr_fft_plan *p, const int16_t *d_iq, long long n_in, float *d_ou
         gp.chunk += gp.chunk & 1;
         const unsigned nb = (unsigned)((frames + gp.chunk - 1) / gp.chunk);
         const size_t lds = 2 * (size_t)(4096 + 256) * sizeof(float) * 2;
-        hipError_t ea = hipFuncSetAttribute((const void *)fft4096_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ea != hipSuccess) return sdr::hip_fail(ea, "fft kernel attribute");
+        if (!p->lds_opt_in) {
+            hipError_t ea = hipFuncSetAttribute((const void *)fft4096_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (ea != hipSuccess) return sdr::hip_fail(ea, "fft kernel attribute");
+            p->lds_opt_in = true;
+        }
         fft4096_pair_kernel<<<nb, 256, lds, st>>>(in, p->d_win, (const cf *)p->d_tw, d_out, gp);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) return sdr::hip_fail(e2, "fft kernel launch");
@@ -679,9 +685,8 @@ extern "C" int sdr_fft_plan_create(int nfft, int hop, const double *window, sdr_
     sdr_fft_plan *p = new sdr_fft_plan();
     p->nfft = nfft; p->hop = hop;
     {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        if (hipGetDevice(&p->device) == hipSuccess && hipGetDeviceProperties(&prop, p->device) == hipSuccess)
             p->n_cu = prop.multiProcessorCount;
     }
     // window table carries the Q11 scale and the 1/N of fftInPlace(x, 1/N): both powers of two
@@ -743,6 +748,7 @@ extern "C" int sdr_fft_execute_i16_host(sdr_fft_plan *p, const int16_t *iq, size
     if ((size_t)frames > frame_capacity) { sdr::set_error("frame capacity %zu < %lld", frame_capacity, frames); return SDR_ECAPACITY; }
     if (frames == 0) return SDR_OK;
     if (!iq || !out) { sdr::set_error("null argument"); return SDR_EINVAL; }
+    if (int rc = sdr::same_device(p->device)) return rc;
     const size_t bin = n_in * 4, bout = (size_t)frames * p->nfft * sizeof(float);
     if (bin > p->cap_in) {
         if (p->d_in) (void)hipFree(p->d_in);
@@ -770,18 +776,19 @@ extern "C" int sdr_fft_time_dev(sdr_fft_plan *p, const int16_t *d_iq, size_t n_i
     if (!p || !d_iq || !d_out || iters <= 0 || !ms_per_launch) { sdr::set_error("bad argument"); return SDR_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const long long frames = frame_count(p, (long long)n_in);
-    hipEvent_t e0, e1;
-    SDR_HIP(hipEventCreate(&e0));
-    SDR_HIP(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = SDR_OK;
-    SDR_HIP(hipEventRecord(e0, st));
-    for (int i = 0; i < iters && rc == SDR_OK; ++i) rc = launch_fft(p, d_iq, (long long)n_in, d_out, frames, st);
-    SDR_HIP(hipEventRecord(e1, st));
-    SDR_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
-    SDR_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    for (int i = 0; e == hipSuccess && i < iters && rc == SDR_OK; ++i) rc = launch_fft(p, d_iq, (long long)n_in, d_out, frames, st);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return sdr::hip_fail(e, "timing events");
     *ms_per_launch = ms / (float)iters;
     return rc;
 }

@@ -1234,9 +1234,14 @@ struct sdr_fir_plan {
     void *d_in = nullptr, *d_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
     int device = 0;
+    mutable bool lds_opt_in = false;   // the kernel's dynamic LDS limit has been raised (once per plan)
 };
 
 namespace {
+
+// the dynamic LDS limit is a property of the kernel, not of the plan: raise it to the whole CU's
+// 160 KB so that plans with different tiles can share a kernel in any order
+constexpr int kLdsPerCu = 160 * 1024;
 
 int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -1280,9 +1285,9 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
 #define SDR_I8(NS, CB)                                                                           \
     do {                                                                                         \
-        if (p->lds_bytes > 64 * 1024)                                                            \
+        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)                                                            \
             (void)hipFuncSetAttribute((const void *)fir_mfma_i8_kernel<NS, CB>,                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes); \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu); \
         fir_mfma_i8_kernel<NS, CB><<<nb, 1024, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale);                \
     } while (0)
@@ -1295,25 +1300,25 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         return hipGetLastError();
     }
     if (p->mfma) {
-        if (p->lds_bytes > 64 * 1024)
+        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)
             (void)hipFuncSetAttribute((const void *)fir_mfma_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
         fir_mfma_kernel<<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), 256, p->lds_bytes, st>>>(
             (const uint32_t *)in, out, p->d_atab, g);
         return hipGetLastError();
     }
     if (p->planar) {
-        if (p->lds_bytes > 64 * 1024)
+        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)
             (void)hipFuncSetAttribute((const void *)fir_planar_kernel<R>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
         fir_planar_kernel<R><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
                                                                            p->d_gtab, g);
         return hipGetLastError();
     }
     if (p->raw) {
-        if (p->lds_bytes > 64 * 1024)
+        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)
             (void)hipFuncSetAttribute((const void *)fir_raw_kernel<R>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
         fir_raw_kernel<R><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
                                                                         p->d_gtab, g);
         return hipGetLastError();
@@ -1321,9 +1326,9 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
     const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
 #define SDR_STREAM(INK, SL)                                                                      \
     do {                                                                                         \
-        if (p->lds_bytes > 64 * 1024)                                                            \
+        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)                                                            \
             (void)hipFuncSetAttribute((const void *)fir_stream_kernel<INK, R, SL>,               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes); \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu); \
         fir_stream_kernel<INK, R, SL><<<nb, p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, g); \
     } while (0)
     const bool small = p->n_inst <= kSlotsSmall;
@@ -1342,6 +1347,7 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
 {
     if (out_end <= out_begin || n_ch == 0) return SDR_OK;
     if (n_ch > 65535) { sdr::set_error("n_channels > 65535"); return SDR_EINVAL; }
+    if (int rc = sdr::same_device(p->device)) return rc;
     const size_t ia = in_elem_bytes(p->input);
     if (((uintptr_t)in) % ia) { sdr::set_error("input pointer not sample aligned"); return SDR_EALIGN; }
     if (((uintptr_t)out) % out_elem_bytes(p->mode)) { sdr::set_error("output pointer misaligned"); return SDR_EALIGN; }
@@ -1384,6 +1390,7 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     default: e = launch_r<8>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
     }
     if (e != hipSuccess) return sdr::hip_fail(e, "fir kernel launch");
+    p->lds_opt_in = true;
     return SDR_OK;
 }
 
@@ -1813,6 +1820,7 @@ extern "C" int sdr_fir_execute_host(sdr_fir_plan *p, const void *in, size_t n_in
     if ((size_t)cnt > out_capacity) { sdr::set_error("output capacity %zu < %lld", out_capacity, cnt); return SDR_ECAPACITY; }
     if (cnt == 0) return SDR_OK;
     if (!out) { sdr::set_error("null output"); return SDR_EINVAL; }
+    if (int rc = sdr::same_device(p->device)) return rc;
     const size_t bin = n_in * in_elem_bytes(p->input), bout = (size_t)cnt * out_elem_bytes(p->mode);
     if (bin > p->cap_in) {
         if (p->d_in) (void)hipFree(p->d_in);
@@ -1840,21 +1848,22 @@ extern "C" int sdr_fir_time_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, 
 {
     if (!p || !d_in || !d_out || iters <= 0 || !ms_per_launch) { sdr::set_error("bad argument"); return SDR_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    SDR_HIP(hipEventCreate(&e0));
-    SDR_HIP(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     const long long cnt = out_count(p, (long long)n_in);
     int rc = SDR_OK;
-    SDR_HIP(hipEventRecord(e0, st));
-    for (int i = 0; i < iters && rc == SDR_OK; ++i)
+    float ms = 0.f;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    for (int i = 0; e == hipSuccess && i < iters && rc == SDR_OK; ++i)
         rc = launch(p, d_in, 0, (long long)n_in, (long long)n_in, 0, cnt, (long long)in_stride,
                     n_channels ? n_channels : 1, d_out, (long long)out_stride, st);
-    SDR_HIP(hipEventRecord(e1, st));
-    SDR_HIP(hipEventSynchronize(e1));
-    float ms = 0.f;
-    SDR_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return sdr::hip_fail(e, "timing events");
     *ms_per_launch = ms / (float)iters;
     return rc;
 }

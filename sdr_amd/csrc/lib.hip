@@ -57,6 +57,18 @@ int ensure_device()
     return check_device(cur);
 }
 
+// A plan's tables and scratch live on the device it was created on; a launch from a thread whose
+// current device is another one would hand that device pointers it may not be able to reach.
+int same_device(int plan_device)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != plan_device) {
+        set_error("plan belongs to device %d but the calling thread's current device is %d (sdr_init / hipSetDevice first)", plan_device, cur);
+        return SDR_EINVAL;
+    }
+    return SDR_OK;
+}
+
 }  // namespace sdr
 
 extern "C" int sdr_init(int device) { return sdr::check_device(device); }
@@ -232,8 +244,9 @@ __global__ void __launch_bounds__(256) synth_fm_kernel(uint32_t *__restrict__ ou
     }
 }
 
-// a8 support: out[i] = in[idx[i]], elements of `ew` 32-bit words (decimate_vec's pick)
-__global__ void __launch_bounds__(256) gather_kernel(const uint32_t *__restrict__ in, int ew,
+// a8 support: out[i] = in[idx[i]], elements of `ew` 32-bit words (decimate_vec's pick); an index
+// outside [0, n_in) gives a zero element instead of a stray read
+__global__ void __launch_bounds__(256) gather_kernel(const uint32_t *__restrict__ in, int ew, size_t n_in,
                                                      const unsigned long long *__restrict__ idx, size_t n,
                                                      uint32_t *__restrict__ out)
 {
@@ -241,7 +254,8 @@ __global__ void __launch_bounds__(256) gather_kernel(const uint32_t *__restrict_
     const size_t total = n * (size_t)ew;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const size_t e = i / ew, w = i - e * ew;
-        out[i] = in[idx[e] * ew + w];
+        const unsigned long long src = idx[e];
+        out[i] = src < n_in ? in[src * ew + w] : 0u;
     }
 }
 
@@ -286,7 +300,7 @@ extern "C" int sdr_audio_u8_dev(const float *d_x, size_t n, float *d_max, uint8_
 {
     if (n == 0) return SDR_OK;
     if (!d_x || !d_max || !d_pcm) { sdr::set_error("null argument"); return SDR_EINVAL; }
-    if (((uintptr_t)d_x) & 3 || ((uintptr_t)d_max) & 3) return SDR_EALIGN;
+    if (((uintptr_t)d_x) & 3 || ((uintptr_t)d_max) & 3) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -302,7 +316,7 @@ extern "C" int sdr_unpack_i16_dev(const int16_t *d_iq, size_t n, float *d_out, v
 {
     if (n == 0) return SDR_OK;
     if (!d_iq || !d_out) { sdr::set_error("null argument"); return SDR_EINVAL; }
-    if (((uintptr_t)d_iq) & 3 || ((uintptr_t)d_out) & 7) return SDR_EALIGN;
+    if (((uintptr_t)d_iq) & 3 || ((uintptr_t)d_out) & 7) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
     unpack_kernel<<<stream_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>((const uint32_t *)d_iq, n, (float2 *)d_out);
@@ -314,7 +328,7 @@ extern "C" int sdr_magnitude_i16_dev(const int16_t *d_iq, size_t n, float *d_mag
 {
     if (n == 0) return SDR_OK;
     if (!d_iq || !d_mag) { sdr::set_error("null argument"); return SDR_EINVAL; }
-    if (((uintptr_t)d_iq) & 3 || ((uintptr_t)d_mag) & 3) return SDR_EALIGN;
+    if (((uintptr_t)d_iq) & 3 || ((uintptr_t)d_mag) & 3) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
     magnitude_kernel<<<stream_grid(n), 256, 0, (hipStream_t)stream>>>((const uint32_t *)d_iq, n, d_mag);
@@ -327,7 +341,7 @@ extern "C" int sdr_frequency_shift_dev(const float *d_in, int is_complex, size_t
 {
     if (n == 0) return SDR_OK;
     if (!d_out) { sdr::set_error("null output"); return SDR_EINVAL; }
-    if (((uintptr_t)d_out) & 7 || (d_in && (((uintptr_t)d_in) & (is_complex ? 7 : 3)))) return SDR_EALIGN;
+    if (((uintptr_t)d_out) & 7 || (d_in && (((uintptr_t)d_in) & (is_complex ? 7 : 3)))) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
     freq_shift_kernel<<<stream_grid(n), 256, 0, (hipStream_t)stream>>>(d_in, is_complex, n, n0, fr, (float2 *)d_out);
@@ -341,7 +355,7 @@ extern "C" int sdr_synth_fm_i16_dev(int16_t *d_iq, size_t n, uint64_t n0, double
 {
     if (n == 0) return SDR_OK;
     if (!d_iq || fs <= 0 || ftone <= 0) { sdr::set_error("bad argument"); return SDR_EINVAL; }
-    if (((uintptr_t)d_iq) & 3) return SDR_EALIGN;
+    if (((uintptr_t)d_iq) & 3) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
     synth_fm_kernel<<<stream_grid(n), 256, 0, (hipStream_t)stream>>>((uint32_t *)d_iq, n, n0, fs, ftone, dev, amp, noise_lsb, seed);
@@ -352,14 +366,13 @@ extern "C" int sdr_synth_fm_i16_dev(int16_t *d_iq, size_t n, uint64_t n0, double
 extern "C" int sdr_gather_dev(const void *d_in, int elem_dwords, size_t n_in, const uint64_t *d_idx,
                               size_t n_idx, void *d_out, void *stream)
 {
-    (void)n_in;
     if (n_idx == 0) return SDR_OK;
     if (!d_in || !d_idx || !d_out || elem_dwords <= 0) { sdr::set_error("bad argument"); return SDR_EINVAL; }
-    if (((uintptr_t)d_in) & 3 || ((uintptr_t)d_out) & 3 || ((uintptr_t)d_idx) & 7) return SDR_EALIGN;
+    if (((uintptr_t)d_in) & 3 || ((uintptr_t)d_out) & 3 || ((uintptr_t)d_idx) & 7) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
     gather_kernel<<<stream_grid(n_idx * elem_dwords), 256, 0, (hipStream_t)stream>>>(
-        (const uint32_t *)d_in, elem_dwords, (const unsigned long long *)d_idx, n_idx, (uint32_t *)d_out);
+        (const uint32_t *)d_in, elem_dwords, n_in, (const unsigned long long *)d_idx, n_idx, (uint32_t *)d_out);
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }

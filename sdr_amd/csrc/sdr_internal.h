@@ -15,6 +15,7 @@ void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
 bool device_ready();          // true once the current device has been verified to be gfx950
 int ensure_device();          // SDR_OK or SDR_ENODEV / SDR_EHIP
+int same_device(int plan_device);   // SDR_OK when the calling thread's current device is the plan's, else SDR_EINVAL
 
 #define SDR_HIP(call)                                         \
     do {                                                      \

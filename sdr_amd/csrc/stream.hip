@@ -146,6 +146,7 @@ extern "C" int sdr_fir_stream_pop(sdr_fir_stream *s, void *out, size_t capacity,
     if (!s || !n_out) { sdr::set_error("bad argument"); return SDR_EINVAL; }
     const int k = s->tail;
     if (!s->busy[k]) { *n_out = 0; sdr::set_error("nothing in flight"); return SDR_EINVAL; }
+    if (s->out_n[k] && !out) { sdr::set_error("null output"); return SDR_EINVAL; }
     if (s->out_n[k] > capacity) { sdr::set_error("output capacity %zu < %zu", capacity, s->out_n[k]); return SDR_ECAPACITY; }
     SDR_HIP(hipEventSynchronize(s->done[k]));
     if (s->out_n[k]) memcpy(out, s->h_out[k], s->out_n[k] * out_bytes(s->mode));

@@ -212,3 +212,25 @@ def test_stream_zero_copy_buffers(sdr, oracle):
     with pytest.raises(sdr.SdrError) as e:
         stream.next_buffer(np.int16, 2 * blk)
     assert e.value.status == sdr.capi.ECAPACITY
+
+
+def test_gather_picks_and_guards_indices(sdr):
+    """a8 support (decimate_vec's pick, bladerf_apt_demod.cpp:374-401): bit-exact picks of 4-, 8- and
+    16-byte elements; an index past the end gives a zero element, never a stray read."""
+    from sdr_amd import capi
+    rng = np.random.default_rng(77)
+    for dwords, dt in ((1, np.float32), (2, np.complex64), (4, np.complex128)):
+        n_in = 1000
+        src = (rng.standard_normal(n_in) + 1j * rng.standard_normal(n_in)).astype(dt) if dwords > 1 \
+            else rng.standard_normal(n_in).astype(dt)
+        idx = rng.integers(0, n_in, 4097).astype(np.uint64)
+        idx[[5, 100, 4096]] = [n_in, n_in + 12345, 2 ** 63]
+        d_in, d_idx = capi.DevBuf.from_numpy(src), capi.DevBuf.from_numpy(idx)
+        d_out = capi.DevBuf(idx.size * 4 * dwords)
+        capi.gather_dev(d_in, dwords, n_in, d_idx, idx.size, d_out)
+        capi.sync()
+        got = d_out.to_numpy(dt, idx.size)
+        ok = idx < n_in
+        want = np.zeros(idx.size, dt)
+        want[ok] = src[idx[ok]]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -36,6 +36,19 @@ inline void check(int status)
     throw std::runtime_error(msg);
 }
 
+// RAII device buffer: freed on every path, exceptions included
+class DevMem {
+public:
+    explicit DevMem(size_t bytes) { check(sdr_dev_alloc(&p_, bytes)); }
+    ~DevMem() { sdr_dev_free(p_); }
+    DevMem(const DevMem&) = delete;
+    DevMem& operator=(const DevMem&) = delete;
+    void* get() const { return p_; }
+    template <class T> T* as() const { return static_cast<T*>(p_); }
+private:
+    void* p_ = nullptr;
+};
+
 // RAII plan
 class FirPlan {
 public:
@@ -103,18 +116,13 @@ inline std::vector<uint8_t> fm_audio_u8(const std::vector<float>& x5, const std:
     const size_t m = plan.out_count(x5.size());
     std::vector<uint8_t> pcm(m);
     if (m == 0) return pcm;
-    void *d_in = nullptr, *d_a = nullptr, *d_pcm = nullptr;
-    int rc = sdr_dev_alloc(&d_in, x5.size() * sizeof(float));
-    if (rc == SDR_OK) rc = sdr_dev_alloc(&d_a, (m + 1) * sizeof(float));       // audio + the max scratch
-    if (rc == SDR_OK) rc = sdr_dev_alloc(&d_pcm, m);
-    if (rc == SDR_OK) rc = sdr_dev_upload(d_in, x5.data(), x5.size() * sizeof(float));
+    DevMem d_in(x5.size() * sizeof(float)), d_a((m + 1) * sizeof(float)), d_pcm(m);   // d_a: audio + the max scratch
+    check(sdr_dev_upload(d_in.get(), x5.data(), x5.size() * sizeof(float)));
     size_t n_out = 0;
-    if (rc == SDR_OK) rc = sdr_fir_execute_dev(plan.get(), d_in, x5.size(), d_a, m, &n_out, nullptr);
-    if (rc == SDR_OK) rc = sdr_audio_u8_dev((const float*)d_a, m, (float*)d_a + m, (uint8_t*)d_pcm, nullptr);
-    if (rc == SDR_OK) rc = sdr_dev_sync();
-    if (rc == SDR_OK) rc = sdr_dev_download(pcm.data(), d_pcm, m);
-    sdr_dev_free(d_in); sdr_dev_free(d_a); sdr_dev_free(d_pcm);
-    check(rc);
+    check(sdr_fir_execute_dev(plan.get(), d_in.get(), x5.size(), d_a.get(), m, &n_out, nullptr));
+    check(sdr_audio_u8_dev(d_a.as<float>(), m, d_a.as<float>() + m, d_pcm.as<uint8_t>(), nullptr));
+    check(sdr_dev_sync());
+    check(sdr_dev_download(pcm.data(), d_pcm.get(), m));
     return pcm;
 }
 
@@ -159,16 +167,12 @@ inline std::vector<std::complex<double>> frequency_shift_impl(const float* in, i
 {
     std::vector<std::complex<double>> res(n);
     if (n == 0) return res;
-    void *d_in = nullptr, *d_out = nullptr;
     const size_t bin = n * (is_complex ? 8 : 4);
-    check(sdr_dev_alloc(&d_in, bin));
-    check(sdr_dev_alloc(&d_out, n * 8));
-    check(sdr_dev_upload(d_in, in, bin));
-    check(sdr_frequency_shift_dev((const float*)d_in, is_complex, n, 0, fr, (float*)d_out, nullptr));
+    DevMem d_in(bin), d_out(n * 8);
+    check(sdr_dev_upload(d_in.get(), in, bin));
+    check(sdr_frequency_shift_dev(d_in.as<float>(), is_complex, n, 0, fr, d_out.as<float>(), nullptr));
     std::vector<std::complex<float>> out(n);
-    check(sdr_dev_download(out.data(), d_out, n * 8));
-    sdr_dev_free(d_in);
-    sdr_dev_free(d_out);
+    check(sdr_dev_download(out.data(), d_out.get(), n * 8));
     for (size_t i = 0; i < n; ++i) res[i] = std::complex<double>(out[i].real(), out[i].imag());
     return res;
 }
@@ -193,12 +197,10 @@ inline std::vector<std::complex<double>> create_freq_rotation(uint64_t N, double
 {
     std::vector<std::complex<double>> res(N);
     if (N == 0) return res;
-    void* d_out = nullptr;
-    sdrhip::check(sdr_dev_alloc(&d_out, N * 8));
-    sdrhip::check(sdr_frequency_shift_dev(nullptr, 1, N, 0, fr, (float*)d_out, nullptr));
+    sdrhip::DevMem d_out(N * 8);
+    sdrhip::check(sdr_frequency_shift_dev(nullptr, 1, N, 0, fr, d_out.as<float>(), nullptr));
     std::vector<std::complex<float>> out(N);
-    sdrhip::check(sdr_dev_download(out.data(), d_out, N * 8));
-    sdr_dev_free(d_out);
+    sdrhip::check(sdr_dev_download(out.data(), d_out.get(), N * 8));
     for (size_t i = 0; i < N; ++i) res[i] = std::complex<double>(out[i].real(), out[i].imag());
     return res;
 }
@@ -221,17 +223,11 @@ std::vector<T> decimate_vec(std::vector<T>& v1, double rate)
     }
     std::vector<T> res(num);
     if (num == 0) return res;
-    void *d_in = nullptr, *d_idx = nullptr, *d_out = nullptr;
-    sdrhip::check(sdr_dev_alloc(&d_in, v1.size() * sizeof(T)));
-    sdrhip::check(sdr_dev_alloc(&d_idx, num * 8));
-    sdrhip::check(sdr_dev_alloc(&d_out, num * sizeof(T)));
-    sdrhip::check(sdr_dev_upload(d_in, v1.data(), v1.size() * sizeof(T)));
-    sdrhip::check(sdr_dev_upload(d_idx, idx.data(), num * 8));
-    sdrhip::check(sdr_gather_dev(d_in, (int)(sizeof(T) / 4), v1.size(), (const uint64_t*)d_idx, num, d_out, nullptr));
-    sdrhip::check(sdr_dev_download(res.data(), d_out, num * sizeof(T)));
-    sdr_dev_free(d_in);
-    sdr_dev_free(d_idx);
-    sdr_dev_free(d_out);
+    sdrhip::DevMem d_in(v1.size() * sizeof(T)), d_idx(num * 8), d_out(num * sizeof(T));
+    sdrhip::check(sdr_dev_upload(d_in.get(), v1.data(), v1.size() * sizeof(T)));
+    sdrhip::check(sdr_dev_upload(d_idx.get(), idx.data(), num * 8));
+    sdrhip::check(sdr_gather_dev(d_in.get(), (int)(sizeof(T) / 4), v1.size(), d_idx.as<uint64_t>(), num, d_out.get(), nullptr));
+    sdrhip::check(sdr_dev_download(res.data(), d_out.get(), num * sizeof(T)));
     return res;
 }
 

@@ -484,6 +484,20 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
             const float4 x = convert_pair<IN>(pre[k], g.mix_fr, tr.W0 + 2LL * sgk[k], g.swap_iq);
             if (a < g.a_gran) tile[a] = x;
         }
+        if constexpr (SLOTS == kSlots) {
+            // tiles with more granules per lane than prefetch registers (decimation factors beyond
+            // ~32 with float input or the mixer): the rest is fetched here, without prefetch
+            for (int k = SLOTS; k < g.n_inst; ++k) {
+                const int a = k * NT + tid;
+                const int sg0 = sample_granule(g, a);
+                const int sg = sg0 < g.s_gran ? sg0 : g.s_gran - 1;
+                P raw;
+                if (tr.fast) raw = *(const P *)(tr.wbase + (unsigned)sg * PairBytes<IN>::value);
+                else raw = fetch_pair_checked<IN>(g, tr.src, tr.W0 + 2LL * sg);
+                const float4 x = convert_pair<IN>(raw, g.mix_fr, tr.W0 + 2LL * sg, g.swap_iq);
+                if (a < g.a_gran) tile[a] = x;
+            }
+        }
         __syncthreads();
         // request the next tile now: its HBM latency is covered by the walk below
         {
@@ -1562,7 +1576,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             }
         }
     }
-    for (int pass = 0; pass < 1 && !bestR; ++pass) {
+    // second pass: shapes that fit no preferred tile (large decimation factors, very long filters)
+    // take any tile the LDS holds, and more granules per lane than the kernel prefetches
+    for (int pass = 0; pass < 2 && !bestR; ++pass) {
         if (d->pipeline == 1 || d->pipeline == 3) continue;
         const bool raw = false;
         const int spg = 2;
@@ -1574,10 +1590,10 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 if (d->threads && d->threads != NT) continue;
                 Geometry gm;
                 if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false)) break;
-                if (gm.n_inst > kSlots) continue;
+                if (gm.n_inst > kSlots && pass == 0) continue;
                 const bool forced = d->threads != 0;
                 // automatic choice: float tiles <= 53 KB (3 workgroups per CU)
-                const int budget = (forced || ni == 2) ? 160 * 1024 : 53 * 1024;
+                const int budget = (forced || ni == 2 || pass == 1) ? 160 * 1024 : 53 * 1024;
                 if (gm.lds_bytes > budget) continue;
                 // SIMD cycles per output: one packed FMA per (sample, output), one ds_read_b128
                 // per granule
@@ -1586,6 +1602,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 if (gm.pad) cost *= 1.1;                                       // padded image: extra index work
                 if (ni > 0) cost *= 1.05;                                      // smaller tiles: more halo
                 if (R == 8) cost *= 2.0;
+                if (gm.n_inst > kSlots) cost *= 1.0 + 0.05 * (gm.n_inst - kSlots);   // unprefetched rest of the tile
                 if (!bestR || cost < best_cost) { best = gm; bestR = R; bestNT = NT; best_raw = raw; best_cost = cost; }
                 break;
             }

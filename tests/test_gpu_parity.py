@@ -751,3 +751,55 @@ def test_fft_long_frames(sdr, oracle, nfft, hop):
         assert np.abs(got[f] - want_db[f])[strong].max() <= 1e-3, (nfft, hop, f)
     with pytest.raises(sdr.SdrError):
         sdr.FftPlan(1 << 21, 1 << 21)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,kind,mix", [(65, 39, "real", 0.0), (199, 41, "real", 0.0371),
+                                          (2047, 32, "i16", -0.123), (2047, 40, "i16", 0.0371),
+                                          (7, 41, "cf32", 0.0), (1000, 25, "i8", 0.0371)])
+def test_large_decimation_float_tiles(sdr, oracle, T, D, kind, mix):
+    """Float-tile kernel beyond its prefetch registers: decimation factors above ~32 (odd ones need
+    two outputs per lane, i.e. D granules per lane) and very long filters at large D take the
+    second geometry pass (any tile the LDS holds, rest of the tile fetched without prefetch)."""
+    rng = np.random.default_rng(T * 1000 + D)
+    n = 150_011
+    h = oracle.create_fir_filter(T, min(0.8 / D, 0.9), "hann")
+    if kind == "i16":
+        raw = rng.integers(-32768, 32768, 2 * n, dtype=np.int16)
+        x, inp = oracle.unpack_scale_i16(raw), sdr.IN_I16_IQ
+    elif kind == "i8":
+        raw = rng.integers(-128, 128, 2 * n, dtype=np.int8)
+        x, inp = oracle.unpack_scale_i8(raw), sdr.IN_I8_IQ
+    elif kind == "cf32":
+        raw = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3).astype(np.complex64)
+        x, inp = raw.astype(np.complex128), sdr.IN_CF32
+    else:
+        raw = (rng.standard_normal(n) * 0.3).astype(np.float32)
+        x, inp = raw.astype(np.complex128), sdr.IN_F32_REAL
+    if mix != 0.0:
+        x = oracle.frequency_shift(x, mix)
+    y = oracle.fir_decimate(x, D, h)
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp, mix_fr=mix)
+    assert plan.info()["kernel"] == "stream"
+    check_linear(plan.execute_host(raw), y, f"T={T} D={D} {kind}")
+    check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=inp, mix_fr=mix).execute_host(raw),
+                 oracle.envelope(y), f"T={T} D={D} {kind} env")
+    got = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=inp, mix_fr=mix).execute_host(raw)
+    assert got.shape == (y.size - 1,) and np.isfinite(got).all()
+
+
+@pytest.mark.gpu
+def test_randomised_shapes(sdr, oracle):
+    """A fixed slice of tools/fuzz_parity.py (random T, D, n, mode, input kind, mixer, kernel choice,
+    taps of mixed magnitude, a random shard cut per case): 400 seeded cases."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    ran = 0
+    for seed in range(7_000_000, 7_000_400):
+        try:
+            ran += fuzz_parity.one_case(np.random.default_rng(seed), seed) == "ok"
+        except sdr.SdrError as e:
+            assert "pipeline 5 needs at least 4 resident samples" in str(e), (seed, str(e))
+    assert ran >= 300

@@ -234,3 +234,16 @@ def test_gather_picks_and_guards_indices(sdr):
         want = np.zeros(idx.size, dt)
         want[ok] = src[idx[ok]]
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_randomised_entry_points(sdr):
+    """A fixed slice of tools/fuzz_more.py: FFT -> dB (random frame length, hop, stream length,
+    window), the block hand-off (random block sizes, copying and zero-copy pushes; bit-identical to
+    the one-shot result for the vector-unit kernels) and batched channels (random counts, strides)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_more
+    for seed in range(9_000_000, 9_000_060):
+        fuzz_more.fft_case(np.random.default_rng(seed), seed)
+        fuzz_more.stream_case(np.random.default_rng(seed), seed)
+        fuzz_more.batched_case(np.random.default_rng(seed), seed)

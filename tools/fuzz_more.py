@@ -1,0 +1,188 @@
+"""Randomised sweeps of the entry points around the FIR plans: FFT -> dB (random frame length, hop,
+stream length, window), the block hand-off (random block sizes, zero-copy or copying push) and
+batched channels (random channel count and strides).  Usage: python tools/fuzz_more.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import sdr_amd as sdr                      # noqa: E402
+from oracle import oracle                  # noqa: E402
+import fuzz_parity as fz                   # noqa: E402
+
+
+def fft_case(rng, seed):
+    nfft = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096, 4096, 8192, 16384]))
+    hop = int(rng.choice([nfft // 2, nfft // 2, nfft, nfft // 4, int(rng.integers(1, 2 * nfft + 1))]))
+    max_frames = max(2, 600_000 // nfft)
+    frames = int(rng.choice([0, 1, 2, 3, int(rng.integers(1, max_frames))]))
+    n = 0 if frames == 0 else nfft + (frames - 1) * hop + int(rng.integers(0, hop))
+    if frames == 0:
+        n = int(rng.integers(0, nfft))
+    wname = rng.choice(["none", "hann", "blackman", "nuttall"])
+    w = None if wname == "none" else oracle.window(str(wname), nfft)
+    tag = f"fft seed={seed} nfft={nfft} hop={hop} n={n} frames={frames} win={wname}"
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        iq = rng.integers(-2048, 2048, 2 * n, dtype=np.int16)
+    elif kind == 1:
+        iq = oracle.synth_fm_i16(n, fs=1.0e6, ftone=2500.0, dev=60000.0, amp=1800.0) if n else np.zeros(0, np.int16)
+        iq = (iq + rng.integers(-3, 4, iq.size)).astype(np.int16)
+    else:
+        iq = rng.integers(-32768, 32768, 2 * n, dtype=np.int16)
+    plan = sdr.FftPlan(nfft, hop, w)
+    assert plan.frame_count(n) == frames, tag
+    got = plan.execute_host(iq).astype(np.float64)
+    if frames == 0:
+        assert got.size == 0, tag
+        return
+    want_db, want_lin = oracle.fft_power_db_i16(iq, nfft, hop, w, linear=True)
+    assert got.shape == want_db.shape, tag
+    lin = 10.0 ** (got / 10.0)
+    peak = want_lin.max(axis=1, keepdims=True)
+    assert np.abs(lin - want_lin).max() <= 1e-5 * peak.max(), tag + " linear"
+    strong = want_lin > peak * 1e-5
+    assert np.abs(got - want_db)[strong].max() <= 1e-3, tag + " dB"
+    plan.destroy()
+
+
+def stream_case(rng, seed):
+    T = int(rng.choice([1, 8, 64, 101, 300, 511, int(rng.integers(1, 400))]))
+    D = int(rng.choice([1, 2, 5, 10, 15, 20, int(rng.integers(1, 30))]))
+    mode = int(rng.choice([sdr.MODE_IQ, sdr.MODE_FM, sdr.MODE_ENV]))
+    kind = int(rng.choice([sdr.IN_I16_IQ, sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ, sdr.IN_CF32, sdr.IN_F32_REAL]))
+    mix = float(rng.choice([0.0, 0.0, 0.0371]))
+    n = int(rng.integers(1, 120_000))
+    max_block = int(rng.choice([64, 1000, 4096, 50_000]))
+    h = fz.random_taps(rng, T, D)
+    tag = f"stream seed={seed} T={T} D={D} mode={mode} in={kind} mix={mix} n={n} max_block={max_block}"
+    if kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI):
+        raw = oracle.synth_fm_i16(n, fs=1.0e6, ftone=3000.0, dev=20000.0, amp=1900.0)
+        raw = (raw + rng.integers(-40, 41, raw.size)).astype(np.int16)
+        per = 2
+    elif kind == sdr.IN_I8_IQ:
+        raw, per = rng.integers(-128, 128, 2 * n, dtype=np.int8), 2
+    elif kind == sdr.IN_CF32:
+        raw, per = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3).astype(np.complex64), 1
+    else:
+        raw, per = (rng.standard_normal(n) * 0.3).astype(np.float32), 1
+    plan = sdr.FirPlan(h, D, mode=mode, input=kind, mix_fr=mix)
+    whole = plan.execute_host(raw)
+    st = sdr.FirStream(plan, max_block)
+    pos, parts, in_flight = 0, [], 0
+    while pos < n:
+        blk = int(min(n - pos, rng.choice([max_block, max_block, 1, 2, 3, int(rng.integers(1, max_block + 1))])))
+        piece = raw[per * pos: per * (pos + blk)]
+        if rng.integers(0, 2):
+            buf = st.next_buffer(raw.dtype, blk * per)
+            buf[:] = piece
+            st.push_buffer(buf, blk)
+        else:
+            st.push(piece)
+        pos += blk
+        in_flight += 1
+        if in_flight == 2:
+            parts.append(st.pop())
+            in_flight -= 1
+    while in_flight:
+        parts.append(st.pop())
+        in_flight -= 1
+    got = np.concatenate(parts) if parts else np.zeros(0, whole.dtype)
+    assert got.shape == whole.shape, tag + f" {got.shape} {whole.shape}"
+    if got.size == 0:
+        return
+    i8 = plan.info()["kernel"] == "mfma_i8"
+    if mode == sdr.MODE_FM:
+        # same inputs, same kernel: only the tile position of an output differs
+        d = np.abs(got.astype(np.float64) - whole.astype(np.float64))
+        d = np.minimum(d, np.abs(1.0 - d))
+        if i8:
+            assert np.mean(d <= 2e-6) > 0.995, tag + f" fm {d.max()}"
+        else:
+            assert np.array_equal(got, whole), tag + f" fm {d.max()}"
+    elif i8:
+        assert np.abs(got - whole).max() <= 2e-6 * max(1.0, float(np.abs(whole).max())), tag
+    else:
+        assert np.array_equal(got, whole), tag + f" {np.abs(got - whole).max()}"
+    st.destroy()
+    plan.destroy()
+
+
+def batched_case(rng, seed):
+    T = int(rng.choice([16, 64, 101, 300, 511]))
+    D = int(rng.choice([2, 5, 8, 10, 15, 20]))
+    mode = int(rng.choice([sdr.MODE_IQ, sdr.MODE_FM, sdr.MODE_ENV]))
+    n_ch = int(rng.choice([1, 2, 7, 37, 64, 200]))
+    n = int(rng.choice([D * 3, 1000, 5120, int(rng.integers(1, 30_000))]))
+    pipe = int(rng.choice([0, 0, 1, 2, 5]))
+    h = fz.random_taps(rng, T, D)
+    tag = f"batched seed={seed} T={T} D={D} mode={mode} n_ch={n_ch} n={n} pipe={pipe}"
+    try:
+        plan = sdr.FirPlan(h, D, mode=mode, pipeline=pipe)
+    except sdr.SdrError:
+        assert pipe != 0, tag
+        return
+    cnt = plan.out_count(n)
+    stride_in = n + int(rng.integers(0, 9))
+    stride_out = cnt + int(rng.integers(0, 5))
+    buf = rng.integers(-32768, 32768, 2 * stride_in * n_ch, dtype=np.int16)
+    eb = 8 if mode == sdr.MODE_IQ else 4
+    dt = np.complex64 if mode == sdr.MODE_IQ else np.float32
+    d_in = sdr.DevBuf.from_numpy(buf)
+    d_out = sdr.DevBuf(max(stride_out * n_ch, 1) * eb)
+    try:
+        plan.execute_batched_dev(d_in, n, stride_in, n_ch, d_out, stride_out)
+    except sdr.SdrError as e:
+        assert pipe == 5 and "at least 4" in str(e), tag + str(e)
+        return
+    sdr.sync()
+    out = d_out.to_numpy(dt, stride_out * n_ch)
+    for c in sorted(set([0, n_ch - 1, int(rng.integers(0, n_ch))])):
+        one = plan.execute_host(buf[2 * c * stride_in: 2 * (c * stride_in + n)])
+        got = out[c * stride_out: c * stride_out + cnt]
+        if plan.info()["kernel"] == "mfma_i8":
+            if mode == sdr.MODE_FM:
+                continue            # noise input: angles ill-conditioned, tile positions differ
+            assert np.abs(got - one).max() <= 2e-6 * max(1.0, float(np.abs(one).max())), tag + f" ch {c}"
+        else:
+            assert np.array_equal(got, one), tag + f" ch {c}"
+    plan.destroy()
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    sdr.init(0)
+    t0 = time.time()
+    last = t0
+    counts = {"fft": 0, "stream": 0, "batched": 0}
+    n_bad = 0
+    i = 0
+    cases = (("fft", fft_case), ("stream", stream_case), ("batched", batched_case))
+    while time.time() - t0 < budget:
+        seed = seed0 * 1_000_003 + i
+        name, fn = cases[i % 3]
+        i += 1
+        try:
+            fn(np.random.default_rng(seed), seed)
+            counts[name] += 1
+        except AssertionError as e:
+            n_bad += 1
+            print("FAIL", str(e)[:400], flush=True)
+        except sdr.SdrError as e:
+            n_bad += 1
+            print("ERROR", name, seed, str(e)[:300], flush=True)
+        if time.time() - last > 30:
+            last = time.time()
+            print(f"... {i} cases, {n_bad} failures", flush=True)
+    print(f"fuzz_more: {counts}, {n_bad} failures", flush=True)
+    sys.exit(1 if n_bad else 0)
+
+
+if __name__ == "__main__":
+    main()

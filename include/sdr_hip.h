@@ -129,7 +129,10 @@ typedef struct sdr_fir_desc {
                              bytes, taps as four base-256 digits, exact int32 accumulation
                              (windows T + 15*D up to 768 samples; int16 without mixer only;
                              leave outputs_per_lane and threads 0).  Chosen automatically where a
-                             measured cost model (tiles vs taps per sample) puts it ahead. */
+                             measured cost model (tiles vs taps per sample) puts it ahead.  Taps
+                             smaller than 2^-31 of the largest one are dropped by the fixed point;
+                             the discriminator outputs of a stream's start-up transient, where
+                             such taps can decide the angle, are recomputed with float32 taps. */
 } sdr_fir_desc;
 
 /* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument

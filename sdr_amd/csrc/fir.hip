@@ -1222,6 +1222,45 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fir_startup_fm_kernel: the discriminator outputs of a stream's start-up transient, recomputed with
+// float32 taps after fir_mfma_i8_kernel.  There |y| is small and the taps
+// below the matrix kernel's fixed-point resolution (2^-31 of the largest tap: the numerically-zero
+// taps of a windowed sinc) decide the angle of an output whose other y is exactly zero, which the
+// reference reports as 0 or +-pi by the signs of its zeros.  One wave per output: the lanes share
+// the taps of y[m] and y[m+1], wave-reduce, lane 0 applies the discriminator.  A few dozen outputs
+// per stream start.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+fir_startup_fm_kernel(const uint32_t *__restrict__ in, float *__restrict__ out,
+                      const float *__restrict__ taps, const FirGeom g, long long m_begin)
+{
+    const int lane = threadIdx.x;
+    const long long m = m_begin + blockIdx.x, ch = blockIdx.y;
+    const uint32_t *src = in + ch * g.in_stride;
+    float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+    const long long n0 = m * g.D, n1 = n0 + g.D;
+    for (int k = lane; k < g.T; k += 64) {
+        const float h = taps[k];
+        const long long s0 = n0 - k, s1 = n1 - k;
+        if (s0 >= g.lo_valid && s0 < g.hi_valid) {
+            const uint32_t w = src[s0];
+            const float xi = g.swap_iq ? hi16(w) : lo16(w), xq = g.swap_iq ? lo16(w) : hi16(w);
+            a0.x = __fmaf_rn(h, xi, a0.x);
+            a0.y = __fmaf_rn(h, xq, a0.y);
+        }
+        if (s1 >= g.lo_valid && s1 < g.hi_valid) {
+            const uint32_t w = src[s1];
+            const float xi = g.swap_iq ? hi16(w) : lo16(w), xq = g.swap_iq ? lo16(w) : hi16(w);
+            a1.x = __fmaf_rn(h, xi, a1.x);
+            a1.y = __fmaf_rn(h, xq, a1.y);
+        }
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) out[ch * g.out_stride + (m - g.out_begin)] = discriminate(a1, a0, g.scale);
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1236,6 +1275,7 @@ struct sdr_fir_plan {
     bool mfma_i8 = false;   // fir_mfma_i8_kernel (byte-split Toeplitz GEMM on the int8 matrix pipe, persistent)
     uint4 *d_atab8 = nullptr;   // its A-operand table (tap digits)
     uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave
+    float *d_ftaps = nullptr;   // float32 taps (Q11 folded) for fir_startup_fm_kernel (discriminator plans)
     int plane_bytes = 0;
     float yscale = 1.f;         // its output scale 2^-(F+11)
     sdr_fir_plan *tiny = nullptr;   // automatic choice only: the VALU plan that takes streams shorter than 4 samples
@@ -1405,6 +1445,15 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     }
     if (e != hipSuccess) return sdr::hip_fail(e, "fir kernel launch");
     p->lds_opt_in = true;
+    if (p->mfma_i8 && p->d_ftaps && p->mode == SDR_MODE_FM && out_begin * p->D < p->T - 1) {
+        // start-up outputs again, with float32 taps (see fir_startup_fm_kernel)
+        long long split = (p->T - 1 + p->D - 1) / p->D + 1;
+        if (split > out_end) split = out_end;
+        fir_startup_fm_kernel<<<dim3((unsigned)(split - out_begin), (unsigned)n_ch), 64, 0, st>>>(
+            (const uint32_t *)base, (float *)out, p->d_ftaps, g, out_begin);
+        e = hipGetLastError();
+        if (e != hipSuccess) return sdr::hip_fail(e, "fir start-up kernel launch");
+    }
     return SDR_OK;
 }
 
@@ -1722,6 +1771,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_atab8, at8.data(), at8.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_btab8, bt8.size() * sizeof(uint4));
     if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_btab8, bt8.data(), bt8.size() * sizeof(uint4), hipMemcpyHostToDevice);
+    if (e == hipSuccess && p->mfma_i8 && p->mode == SDR_MODE_FM) e = hipMalloc((void **)&p->d_ftaps, hf.size() * sizeof(float));
+    if (e == hipSuccess && p->d_ftaps) e = hipMemcpy(p->d_ftaps, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && p->mfma) e = hipMalloc((void **)&p->d_atab, at.size() * sizeof(float4));
     if (e == hipSuccess && p->mfma) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_gtab, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -1746,6 +1797,7 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (p->tiny) (void)sdr_fir_plan_destroy(p->tiny);
     if (p->d_atab8) (void)hipFree(p->d_atab8);
     if (p->d_btab8) (void)hipFree(p->d_btab8);
+    if (p->d_ftaps) (void)hipFree(p->d_ftaps);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     delete p;

@@ -803,3 +803,26 @@ def test_randomised_shapes(sdr, oracle):
         except sdr.SdrError as e:
             assert "pipeline 5 needs at least 4 resident samples" in str(e), (seed, str(e))
     assert ran >= 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipe", [0, 5])
+def test_matrix_kernel_startup_zero_vector_angle(sdr, oracle, pipe):
+    """Found by tools/fuzz_parity.py: with a Hann design h[0] is exactly zero, so y[0] = 0, and with
+    fc*t an integer at t = -(T-1)/2 + 1 the next tap is ~1e-20 -- below the int8 matrix kernel's
+    fixed point -- so y[1] consists of a tap that kernel drops.  The reference's first discriminator
+    output is then +-pi*scale by the signs of its zeros; fir_startup_fm_kernel recomputes the start-up
+    outputs with float32 taps."""
+    T, D, n = 193, 1, 50_989
+    h = oracle.create_fir_filter(T, 0.8, "hann")
+    assert h[0] == 0.0 and 0.0 < abs(h[1]) < abs(h).max() * 2.0 ** -40
+    iq = oracle.synth_fm_i16(n, fs=1.0e6, ftone=3000.0, dev=20000.0, amp=1900.0)
+    iq[1] = 7                        # Q of sample 0 > 0: the product's real part becomes -0
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=pipe)
+    assert plan.info()["kernel"] == "mfma_i8"
+    y = oracle.fir_decimate(oracle.unpack_scale_i16(iq), D, h)
+    want = oracle.polar_discriminator(y, 1 / TWO_PI)
+    assert y[0] == 0 and y[1] != 0 and abs(want[0]) == 0.5
+    got = plan.execute_host(iq)
+    assert got[0] == np.float32(want[0])
+    check_fm(got[T:], want[T:], y[T:], 1 / TWO_PI, "past the transient")

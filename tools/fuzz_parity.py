@@ -108,8 +108,25 @@ def one_case(rng, case_seed):
             check_fm(got, want, y, scale, tag)
         else:
             assert got.shape == want.shape, tag     # noise input: angles are ill-conditioned; shape only
-    # a random shard cut of the same stream must reproduce the whole
+    # the same stream at a random sample offset inside a device buffer, outputs at a random element
+    # offset inside a buffer of sentinels: identical results, nothing written outside [0, cnt)
     cnt = got.size
+    if n > 0:
+        isz = raw.itemsize * (2 if kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ) else 1)
+        osz = 8 if mode == sdr.MODE_IQ else 4
+        so, oo = int(rng.integers(0, 8)), int(rng.integers(0, 6))
+        hostbuf = np.zeros(so * isz + raw.nbytes + 64, np.uint8)
+        hostbuf[so * isz: so * isz + raw.nbytes] = raw.view(np.uint8).reshape(-1)
+        d_in = sdr.DevBuf.from_numpy(hostbuf)
+        guard = np.full((oo + cnt + 8) * (osz // 4), 0x7FC0DEAD, np.uint32)
+        d_out = sdr.DevBuf.from_numpy(guard)
+        assert plan.execute_dev(d_in.at(so * isz), n, d_out.at(oo * osz), cnt) == cnt, tag
+        sdr.sync()
+        back = d_out.to_numpy(np.uint32, guard.size)
+        w = osz // 4
+        assert np.all(back[: oo * w] == 0x7FC0DEAD) and np.all(back[(oo + cnt) * w:] == 0x7FC0DEAD), tag + f" wrote outside its outputs (so={so} oo={oo})"
+        assert np.array_equal(back[oo * w: (oo + cnt) * w], got.view(np.uint32).reshape(-1)), tag + f" differs at pointer offsets so={so} oo={oo}"
+    # a random shard cut of the same stream must reproduce the whole
     if cnt >= 2 and kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI):
         ob = int(rng.integers(0, cnt - 1))
         oe = int(rng.integers(ob + 1, cnt + 1))

@@ -52,13 +52,16 @@ def random_taps(rng, T, D):
 
 def one_case(rng, case_seed):
     T = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 65, 100, 128, 199, 256, 300, 511, 640, 1000, 2047,
-                        int(rng.integers(1, 700))]))
+                        int(rng.integers(1, 700)), int(rng.integers(1, 700)),
+                        int(rng.choice([4096, 8191, 16384]))]))
     D = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 10, 12, 15, 16, 20, 25, 32, 40, int(rng.integers(1, 48))]))
     n = int(rng.choice([0, 1, 3, D, D + 1, T, T + D, 4 * D * 511, 5120 * 3 + 1,
                         int(rng.integers(1, 200_000)), int(rng.integers(1, 200_000))]))
-    mode = int(rng.choice([sdr.MODE_IQ, sdr.MODE_FM, sdr.MODE_ENV]))
+    mode = int(rng.choice([sdr.MODE_IQ, sdr.MODE_FM, sdr.MODE_ENV, sdr.MODE_REAL]))
     kind = int(rng.choice([sdr.IN_I16_IQ, sdr.IN_I16_IQ, sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ,
                            sdr.IN_CF32, sdr.IN_F32_REAL]))
+    if T > 2047:
+        n = min(n, 40_000)
     mix = float(rng.choice([0.0, 0.0, 0.0371, -0.123]))
     pipe = int(rng.choice([0, 0, 0, 1, 2, 3, 5]))
     if (mix != 0.0 or kind not in (sdr.IN_I16_IQ, sdr.IN_I16_QI)) and pipe not in (0, 2):
@@ -93,7 +96,8 @@ def one_case(rng, case_seed):
     try:
         plan = sdr.FirPlan(h, D, mode=mode, input=kind, scale=scale, mix_fr=mix, pipeline=pipe)
     except sdr.SdrError as e:
-        assert e.status == sdr.capi.EINVAL and pipe != 0, tag + f" plan refused: {e}"
+        lds_limit = T == 16384 and D > 34 and (mix != 0.0 or kind not in (sdr.IN_I16_IQ, sdr.IN_I16_QI))
+        assert e.status == sdr.capi.EINVAL and (pipe != 0 or lds_limit), tag + f" plan refused: {e}"
         return "refused"
     tag += f" kernel={plan.info()['kernel']}"
     y = oracle.fir_decimate(x, D, h)
@@ -102,6 +106,8 @@ def one_case(rng, case_seed):
         check_linear(got, y, tag)
     elif mode == sdr.MODE_ENV:
         check_linear(got, oracle.envelope(y), tag)
+    elif mode == sdr.MODE_REAL:
+        check_linear(got, np.ascontiguousarray(y.real), tag)
     else:
         want = oracle.polar_discriminator(y, scale)
         if kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI) and mix == 0.0:

@@ -110,8 +110,8 @@ typedef struct sdr_fir_desc {
     int decim;          /* D >= 1 */
     int n_taps;         /* 1 <= T <= 16384; NO "T % D == 0" restriction.  A tile of
                            T + 63*D (*2 for odd D) samples has to fit the 160 KB of LDS: float
-                           input or the mixer (8 B per sample) at 16384 taps stops at D = 34 for odd
-                           D, SDR_EINVAL beyond */
+                           input or the mixer (8 B per sample) at 16384 taps stops near D = 30 for
+                           odd D, SDR_EINVAL beyond */
     const double *taps; /* host, T doubles (rounded to float32 on upload; pipeline 5: to 31-bit fixed point) */
     double scale;       /* FM: discriminator scale, e.g. 1/(2*pi) (bladerf_apt_demod.cpp:560) */
     double mix_fr;      /* != 0: multiply x[n] by exp(+j*2*pi*mix_fr*n) before the FIR

@@ -76,6 +76,8 @@ struct FirGeom {
     int tiles_per_ch;
     int tiles_per_xcd;      // ceil(tiles_per_ch / 8)
     int total_tiles;
+    int ph_off;             // mixer: offset (floats) of the phasor tables behind the tap table
+    int n_ph_hi;            // mixer: entries of the coarse table (tile offsets 0, 64, 128, ...)
 };
 
 // kernel-side input kinds (Q-first int16 is IN_I16 with FirGeom::swap_iq)
@@ -416,6 +418,23 @@ __device__ __forceinline__ float4 convert_pair(const typename RawPair<IN>::type 
     return make_float4(x0.x, x0.y, x1.x, x1.y);
 }
 
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(__fmaf_rn(a.x, b.x, -(a.y * b.y)), __fmaf_rn(a.x, b.y, a.y * b.x));
+}
+
+// the sample pair x (tile offsets i, i+1; i even) times the mixer phasors B * HI[i >> 6] * LO[i & 63 (+1)]
+template <int IN>
+__device__ __forceinline__ float4 rotate_pair(float4 x, float2 B, const float2 *ph_hi, const float2 *ph_lo, int i)
+{
+    const float2 bh = cmulf(B, ph_hi[i >> 6]);
+    const float4 lo = *(const float4 *)(ph_lo + (i & 63));
+    const float2 p0 = cmulf(bh, make_float2(lo.x, lo.y)), p1 = cmulf(bh, make_float2(lo.z, lo.w));
+    if (IN == IN_REAL) return make_float4(x.x * p0.x, x.x * p0.y, x.z * p1.x, x.z * p1.y);
+    const float2 y0 = cmulf(make_float2(x.x, x.y), p0), y1 = cmulf(make_float2(x.z, x.w), p1);
+    return make_float4(y0.x, y0.y, y1.x, y1.y);
+}
+
 struct TileRef { long long ch, M0, W0; const void *src; const unsigned char *wbase; bool fast; };
 
 template <int IN>
@@ -473,15 +492,34 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
         }
     };
 
+    // Mixer: exp(j*2*pi*fr*s) for sample s = W0 + i of a tile is B * HI[i >> 6] * LO[i & 63], with
+    // B = the phasor of the tile's first sample (phase reduced in double, one sincos per tile) and
+    // two small tables built on the host in double, kept in LDS: three complex products per sample
+    // pair instead of a double-precision phase and a sincos per sample (which cost more than the
+    // filter itself at 34 taps per sample).  Rounding: three float32 products, ~2e-7.
+    const bool mixing = g.mix_fr != 0.0;
+    float2 *ph_hi = (float2 *)(smem + (size_t)g.a_gran * 16 + (size_t)(NT + 2) * 8);
+    float2 *ph_lo = ph_hi + g.n_ph_hi;
+    if (mixing) {
+        const float2 *src = (const float2 *)(gtab + g.ph_off);
+        for (int i = tid; i < g.n_ph_hi + 64; i += NT) ph_hi[i] = src[i];
+    }
+
     int t = blockIdx.x;
     if (t < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, t, g.per_tile));
     for (; t < g.total_tiles; t += gridDim.x) {
         const TileRef tr = tile_ref<IN>(g, in, t, g.per_tile);
         __syncthreads();                         // every lane has finished with the previous tile
+        float2 B = make_float2(1.f, 0.f);
+        if (mixing) {
+            const double ph = g.mix_fr * (double)tr.W0;
+            sincospif(2.0f * (float)(ph - rint(ph)), &B.y, &B.x);
+        }
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             const int a = k * NT + tid;
-            const float4 x = convert_pair<IN>(pre[k], g.mix_fr, tr.W0 + 2LL * sgk[k], g.swap_iq);
+            float4 x = convert_pair<IN>(pre[k], 0.0, 0, g.swap_iq);
+            if (mixing) x = rotate_pair<IN>(x, B, ph_hi, ph_lo, 2 * sgk[k]);
             if (a < g.a_gran) tile[a] = x;
         }
         if constexpr (SLOTS == kSlots) {
@@ -494,7 +532,8 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
                 P raw;
                 if (tr.fast) raw = *(const P *)(tr.wbase + (unsigned)sg * PairBytes<IN>::value);
                 else raw = fetch_pair_checked<IN>(g, tr.src, tr.W0 + 2LL * sg);
-                const float4 x = convert_pair<IN>(raw, g.mix_fr, tr.W0 + 2LL * sg, g.swap_iq);
+                float4 x = convert_pair<IN>(raw, 0.0, 0, g.swap_iq);
+                if (mixing) x = rotate_pair<IN>(x, B, ph_hi, ph_lo, 2 * sg);
                 if (a < g.a_gran) tile[a] = x;
             }
         }
@@ -1283,6 +1322,7 @@ struct sdr_fir_plan {
     int spg;                // samples per LDS granule: 4 (raw) / 2 (stream)
     int Tback, Lw4, ngran, q, pad, s_gran, a_gran, n_inst, lds_bytes;
     int stream_blocks = 0;  // persistent grid: CUs x resident workgroups per CU
+    int ph_off = 0, n_ph_hi = 0;   // mixer phasor tables behind the tap table (float-tile kernel)
     float *d_gtab = nullptr;
     // staging buffers for the *_host entry point
     void *d_in = nullptr, *d_out = nullptr;
@@ -1303,7 +1343,10 @@ struct Geometry { int Tback, Lw4, U, ngran, look, q, pad, s_gran, a_gran, n_inst
 
 // Tile geometry for (T, D, R, NT) with spg samples per LDS granule.  Returns false when the lane
 // stride is not a whole number of granules.
-bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *o, bool planar = false)
+// entries of the coarse mixer phasor table for a tile of s_gran 2-sample granules (even count)
+int ph_hi_entries(int s_gran) { return ((2 * s_gran) / 64 + 2 + 1) & ~1; }
+
+bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *o, bool planar = false, bool mixer = false)
 {
     if (((long long)D * R) % spg) return false;
     o->Tback = roundup(T - 1, 4);
@@ -1325,6 +1368,7 @@ bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *
     o->a_gran = stream ? roundup(a, NT) : a;
     o->n_inst = (o->a_gran + NT - 1) / NT;
     o->lds_bytes = o->a_gran * (planar ? 32 : 16) + (NT + 2) * 8;
+    if (mixer) o->lds_bytes += (ph_hi_entries(o->s_gran) + 64) * 8;
     return true;
 }
 
@@ -1425,6 +1469,7 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.magic_q = (unsigned)((0x100000000ULL + (unsigned)p->q - 1) / (unsigned)p->q);
     g.s_gran = p->s_gran; g.a_gran = p->a_gran; g.n_inst = p->n_inst; g.mode = p->mode;
     g.swap_iq = (p->input == SDR_IN_I16_QI) ? 1 : 0;
+    g.ph_off = p->ph_off; g.n_ph_hi = p->n_ph_hi;
     g.scale = (float)p->scale;
     // with the discriminator a tile's last lane only supplies its neighbour's successor y
     const long long per_tile = (long long)(p->mode == SDR_MODE_FM ? p->NT - 1 : p->NT) * p->R;
@@ -1638,7 +1683,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 const int NT = NTs[ni];
                 if (d->threads && d->threads != NT) continue;
                 Geometry gm;
-                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false)) break;
+                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false, d->mix_fr != 0.0)) break;
                 if (gm.n_inst > kSlots && pass == 0) continue;
                 const bool forced = d->threads != 0;
                 // automatic choice: float tiles <= 53 KB (3 workgroups per CU)
@@ -1694,6 +1739,20 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             const long long i = (long long)p->D * r + p->Tback - (long long)j;
             if (i >= 0 && i < p->T) gt[j * p->R + r] = hf[i];
         }
+    if (!p->raw && p->mix_fr != 0.0) {
+        // mixer phasor tables (see fir_stream_kernel), phases reduced in double
+        while (gt.size() % 4) gt.push_back(0.0f);                 // 16-byte aligned
+        p->ph_off = (int)gt.size();
+        p->n_ph_hi = ph_hi_entries(p->s_gran);
+        auto phasor = [&](long long i) {
+            const double ph = p->mix_fr * (double)i;
+            const double f = ph - std::rint(ph);
+            gt.push_back((float)std::cos(2.0 * M_PI * f));
+            gt.push_back((float)std::sin(2.0 * M_PI * f));
+        };
+        for (int j = 0; j < p->n_ph_hi; ++j) phasor(64LL * j);
+        for (int i = 0; i < 64; ++i) phasor(i);
+    }
     std::vector<float4> at;
     if (p->mfma) {
         // atab[q][lane]: the four taps lane (i = lane % 16, kq = lane / 16) multiplies with window

@@ -96,7 +96,7 @@ def one_case(rng, case_seed):
     try:
         plan = sdr.FirPlan(h, D, mode=mode, input=kind, scale=scale, mix_fr=mix, pipeline=pipe)
     except sdr.SdrError as e:
-        lds_limit = T == 16384 and D > 34 and (mix != 0.0 or kind not in (sdr.IN_I16_IQ, sdr.IN_I16_QI))
+        lds_limit = T == 16384 and D > 28 and (mix != 0.0 or kind not in (sdr.IN_I16_IQ, sdr.IN_I16_QI))
         assert e.status == sdr.capi.EINVAL and (pipe != 0 or lds_limit), tag + f" plan refused: {e}"
         return "refused"
     tag += f" kernel={plan.info()['kernel']}"

@@ -154,8 +154,8 @@ def one_case(rng, case_seed):
             allowed = abs(scale) * 2.0 * 4e-6 * max(1.0, float(mag.max())) / pm + 4e-6 * fs
             assert not (d > allowed).any(), tag + f" shard [{ob},{oe}) fm {d.max()}"
         else:
-            fsl = max(1.0, float(np.abs(whole).max()))
-            assert np.abs(part - whole).max() <= 4e-6 * fsl, tag + f" shard [{ob},{oe})"
+            fsl = max(1.0, float(np.abs(got).max()))        # full scale of the stream, not of the cut
+            assert np.abs(part - whole).max() <= 4e-6 * fsl, tag + f" shard [{ob},{oe}) {np.abs(part - whole).max()} fs {fsl}"
     plan.destroy()
     return "ok"
 

@@ -274,38 +274,51 @@ __device__ __forceinline__ void walk_touch(const uint4 (&v)[U], const float (&t)
                      "s"(t[k + 5]), "s"(t[k + 6]), "s"(t[k + 7]));
 }
 
-template <int SPG, int R, int U>
-__device__ __forceinline__ void walk_fma(const uint4 (&v)[U], const float (&t)[SPG * R * U],
+template <int SPG, int R, int U, bool REALT>
+__device__ __forceinline__ void walk_fma(const uint4 (&v)[U], const float (&t)[(REALT ? 2 : 1) * SPG * R * U],
                                          float2 (&acc)[R])
 {
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-        float xi[SPG], xq[SPG];
-        if (SPG == 4) {
-            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        if constexpr (REALT) {
+            // four real samples, complex taps (the mixer folded into them): acc += x * (tr, ti)
+            const float x[4] = {__uint_as_float(v[k].x), __uint_as_float(v[k].y), __uint_as_float(v[k].z), __uint_as_float(v[k].w)};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { xi[u] = lo16(w[u]); xq[u] = hi16(w[u]); }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = 2 * ((k * 4 + u) * R + r);
+                    acc[r].x = __fmaf_rn(x[u], t[i], acc[r].x);
+                    acc[r].y = __fmaf_rn(x[u], t[i + 1], acc[r].y);
+                }
         } else {
-            xi[0] = __uint_as_float(v[k].x); xq[0] = __uint_as_float(v[k].y);
-            xi[1] = __uint_as_float(v[k].z); xq[1] = __uint_as_float(v[k].w);
-        }
+            float xi[SPG], xq[SPG];
+            if (SPG == 4) {
+                const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
-        for (int u = 0; u < SPG; ++u)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float h = t[(k * SPG + u) * R + r];
-                acc[r].x = __fmaf_rn(h, xi[u], acc[r].x);
-                acc[r].y = __fmaf_rn(h, xq[u], acc[r].y);
+                for (int u = 0; u < 4; ++u) { xi[u] = lo16(w[u]); xq[u] = hi16(w[u]); }
+            } else {
+                xi[0] = __uint_as_float(v[k].x); xq[0] = __uint_as_float(v[k].y);
+                xi[1] = __uint_as_float(v[k].z); xq[1] = __uint_as_float(v[k].w);
             }
+#pragma unroll
+            for (int u = 0; u < SPG; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float h = t[(k * SPG + u) * R + r];
+                    acc[r].x = __fmaf_rn(h, xi[u], acc[r].x);
+                    acc[r].y = __fmaf_rn(h, xq[u], acc[r].y);
+                }
+        }
     }
 }
 
-template <int SPG, int R, bool PAD>
+template <int SPG, int R, bool PAD, bool REALT>
 __device__ __forceinline__ void walk_p(const FirGeom &g, const uint4 *lds4,
                                        const float *__restrict__ gtab, int tid, float2 (&acc)[R])
 {
     constexpr int U = Walk<SPG, R>::U;
-    constexpr int N = Walk<SPG, R>::N;
+    constexpr int N = (REALT ? 2 : 1) * Walk<SPG, R>::N;    // floats of taps per step
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
     const uint4 *lane_base = lds4 + tid * (g.q + (PAD ? 1 : 0));
@@ -320,22 +333,22 @@ __device__ __forceinline__ void walk_p(const FirGeom &g, const uint4 *lds4,
         walk_load<U, PAD>(vb, lane_base, (s + 1) * U, g);
         walk_taps<N>(tb, gtab + (size_t)(s + 1) * N);
         __builtin_amdgcn_sched_barrier(0);
-        walk_fma<SPG, R, U>(va, ta, acc);
+        walk_fma<SPG, R, U, REALT>(va, ta, acc);
         walk_touch<U, N>(vb, tb);
         __builtin_amdgcn_sched_barrier(0);
         walk_load<U, PAD>(va, lane_base, (s + 2) * U, g);      // look-ahead step (zero taps at the end)
         walk_taps<N>(ta, gtab + (size_t)(s + 2) * N);
         __builtin_amdgcn_sched_barrier(0);
-        walk_fma<SPG, R, U>(vb, tb, acc);
+        walk_fma<SPG, R, U, REALT>(vb, tb, acc);
     }
 }
 
-template <int SPG, int R>
+template <int SPG, int R, bool REALT = false>
 __device__ __forceinline__ void walk(const FirGeom &g, const uint4 *lds4,
                                      const float *__restrict__ gtab, int tid, float2 (&acc)[R])
 {
-    if (g.pad) walk_p<SPG, R, true>(g, lds4, gtab, tid, acc);
-    else walk_p<SPG, R, false>(g, lds4, gtab, tid, acc);
+    if (g.pad) walk_p<SPG, R, true, REALT>(g, lds4, gtab, tid, acc);
+    else walk_p<SPG, R, false, REALT>(g, lds4, gtab, tid, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -345,11 +358,14 @@ __device__ __forceinline__ void walk(const FirGeom &g, const uint4 *lds4,
 template <int IN> struct RawPair;                        // two consecutive input samples
 template <> struct RawPair<IN_I16> { typedef uint2 type; };
 template <> struct RawPair<IN_CF32> { typedef float4 type; };
-template <> struct RawPair<IN_REAL> { typedef float2 type; };
+template <> struct RawPair<IN_REAL> { typedef float4 type; };   // four: real tiles hold 4 samples per granule
 template <> struct RawPair<IN_I8> { typedef uint32_t type; };
 
 // bytes of one RawPair
-template <int IN> struct PairBytes { static constexpr unsigned value = (IN == IN_CF32) ? 16u : (IN == IN_I8 ? 4u : 8u); };
+template <int IN> struct PairBytes { static constexpr unsigned value = (IN == IN_CF32 || IN == IN_REAL) ? 16u : (IN == IN_I8 ? 4u : 8u); };
+// samples per LDS granule of the float-tile kernel: two complex samples, or four real ones (real
+// input stays real in LDS; the mixer is folded into complex taps, see fir_stream_kernel)
+template <int IN> struct TileSpg { static constexpr int value = (IN == IN_REAL) ? 4 : 2; };
 
 // Slow path for tiles that touch the ends of the valid window or a misaligned stream: every
 // sample predicated on its own.
@@ -366,6 +382,14 @@ fetch_pair_checked(const FirGeom &g, const void *__restrict__ src, long long s)
         const float2 b = v1 ? ((const float2 *)src)[s + 1] : make_float2(0.f, 0.f);
         float4 r = make_float4(a.x, a.y, b.x, b.y);
         memcpy(&p, &r, sizeof(p));
+    } else if (IN == IN_REAL) {
+        float r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long su = s + u;
+            r[u] = (su >= g.lo_valid && su < g.hi_valid) ? ((const float *)src)[su] : 0.f;
+        }
+        memcpy(&p, r, sizeof(p));
     } else if (IN == IN_I8) {
         const uint32_t a = v0 ? ((const uint16_t *)src)[s] : 0u;
         const uint32_t b = v1 ? ((const uint16_t *)src)[s + 1] : 0u;
@@ -410,9 +434,8 @@ __device__ __forceinline__ float4 convert_pair(const typename RawPair<IN>::type 
         x0 = make_float2(w.x, w.y);
         x1 = make_float2(w.z, w.w);
     } else {
-        float2 w; memcpy(&w, &p, sizeof(w));
-        x0 = make_float2(w.x, 0.f);
-        x1 = make_float2(w.y, 0.f);
+        float4 w; memcpy(&w, &p, sizeof(w));           // real tile: four samples, stored as they are
+        return w;
     }
     if (fr != 0.0) { x0 = mix(x0, fr, s); x1 = mix(x1, fr, s + 1); }
     return make_float4(x0.x, x0.y, x1.x, x1.y);
@@ -430,7 +453,6 @@ __device__ __forceinline__ float4 rotate_pair(float4 x, float2 B, const float2 *
     const float2 bh = cmulf(B, ph_hi[i >> 6]);
     const float4 lo = *(const float4 *)(ph_lo + (i & 63));
     const float2 p0 = cmulf(bh, make_float2(lo.x, lo.y)), p1 = cmulf(bh, make_float2(lo.z, lo.w));
-    if (IN == IN_REAL) return make_float4(x.x * p0.x, x.x * p0.y, x.z * p1.x, x.z * p1.y);
     const float2 y0 = cmulf(make_float2(x.x, x.y), p0), y1 = cmulf(make_float2(x.z, x.w), p1);
     return make_float4(y0.x, y0.y, y1.x, y1.y);
 }
@@ -450,12 +472,13 @@ __device__ __forceinline__ TileRef tile_ref(const FirGeom &g, const void *__rest
     r.src = (const unsigned char *)in + (size_t)((long long)ch * g.in_stride) * esz;
     r.wbase = (const unsigned char *)r.src + (size_t)r.W0 * esz;          // sample W0
     // fast path: the whole staged window is valid and pairs are naturally aligned
-    r.fast = (r.W0 >= g.lo_valid) && (r.W0 + 2LL * g.s_gran <= g.hi_valid) &&
+    r.fast = (r.W0 >= g.lo_valid) && (r.W0 + (long long)TileSpg<IN>::value * g.s_gran <= g.hi_valid) &&
              ((((uintptr_t)r.src) & (IN == IN_CF32 ? 15 : (IN == IN_I8 ? 3 : 7))) == 0);
     return r;
 }
 
-constexpr int kSlotsSmall = 12, kSlots = 32;   // 2-sample granules one lane stages per tile
+constexpr int kSlotsSmall = 12, kSlots = 32;   // granules one lane stages per tile (prefetch registers)
+constexpr int kSlotsReal = 20;                 // real tiles: 16 bytes per slot, D*R/4 slots per lane
 
 template <int IN, int R, int SLOTS>
 __global__ void __launch_bounds__(256, (SLOTS <= kSlotsSmall ? 3 : 2))
@@ -463,6 +486,7 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
                   const float *__restrict__ gtab, const FirGeom g)
 {
     typedef typename RawPair<IN>::type P;
+    constexpr int SPG = TileSpg<IN>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int NT = blockDim.x;
@@ -488,7 +512,7 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
         } else {
 #pragma unroll
             for (int k = 0; k < SLOTS; ++k)
-                pre[k] = fetch_pair_checked<IN>(g, tr.src, tr.W0 + 2LL * sgk[k]);
+                pre[k] = fetch_pair_checked<IN>(g, tr.src, tr.W0 + (long long)SPG * sgk[k]);
         }
     };
 
@@ -497,7 +521,10 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
     // two small tables built on the host in double, kept in LDS: three complex products per sample
     // pair instead of a double-precision phase and a sincos per sample (which cost more than the
     // filter itself at 34 taps per sample).  Rounding: three float32 products, ~2e-7.
-    const bool mixing = g.mix_fr != 0.0;
+    // Real input stays real in LDS (four samples per granule, half the LDS traffic of the walk) and
+    // the mixer moves into the taps: y[m] = e^{j w m D} * sum_i (h[i] e^{-j w i}) x[mD - i], complex
+    // taps built on the host, one rotation per output afterwards (none for the envelope).
+    const bool mixing = (IN != IN_REAL) && g.mix_fr != 0.0;
     float2 *ph_hi = (float2 *)(smem + (size_t)g.a_gran * 16 + (size_t)(NT + 2) * 8);
     float2 *ph_lo = ph_hi + g.n_ph_hi;
     if (mixing) {
@@ -531,7 +558,7 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
                 const int sg = sg0 < g.s_gran ? sg0 : g.s_gran - 1;
                 P raw;
                 if (tr.fast) raw = *(const P *)(tr.wbase + (unsigned)sg * PairBytes<IN>::value);
-                else raw = fetch_pair_checked<IN>(g, tr.src, tr.W0 + 2LL * sg);
+                else raw = fetch_pair_checked<IN>(g, tr.src, tr.W0 + (long long)SPG * sg);
                 float4 x = convert_pair<IN>(raw, 0.0, 0, g.swap_iq);
                 if (mixing) x = rotate_pair<IN>(x, B, ph_hi, ph_lo, 2 * sg);
                 if (a < g.a_gran) tile[a] = x;
@@ -546,9 +573,18 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
         __builtin_amdgcn_sched_barrier(0);
 
         float2 acc[R];
-        walk<2, R>(g, (const uint4 *)tile, gtab, tid, acc);
+        walk<SPG, R, IN == IN_REAL>(g, (const uint4 *)tile, gtab, tid, acc);
 
         const long long m0 = tr.M0 + (long long)tid * R;
+        if (IN == IN_REAL && g.mix_fr != 0.0 && g.mode != SDR_MODE_ENV) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double ph = g.mix_fr * (double)((m0 + r) * g.D);
+                float2 P;
+                sincospif(2.0f * (float)(ph - rint(ph)), &P.y, &P.x);
+                acc[r] = cmulf(acc[r], P);
+            }
+        }
         float2 ynext = make_float2(0.f, 0.f);
         if (g.mode == SDR_MODE_FM) {
             ybuf[tid] = acc[0];
@@ -1433,7 +1469,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
     if (p->input == SDR_IN_I16_IQ || p->input == SDR_IN_I16_QI) { if (small) SDR_STREAM(IN_I16, kSlotsSmall); else SDR_STREAM(IN_I16, kSlots); }
     else if (p->input == SDR_IN_I8_IQ) { if (small) SDR_STREAM(IN_I8, kSlotsSmall); else SDR_STREAM(IN_I8, kSlots); }
     else if (p->input == SDR_IN_CF32) { if (small) SDR_STREAM(IN_CF32, kSlotsSmall); else SDR_STREAM(IN_CF32, kSlots); }
-    else { if (small) SDR_STREAM(IN_REAL, kSlotsSmall); else SDR_STREAM(IN_REAL, kSlots); }
+    else { if (p->n_inst <= kSlotsReal) SDR_STREAM(IN_REAL, kSlotsReal); else SDR_STREAM(IN_REAL, kSlots); }
 #undef SDR_STREAM
     return hipGetLastError();
 }
@@ -1675,7 +1711,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     for (int pass = 0; pass < 2 && !bestR; ++pass) {
         if (d->pipeline == 1 || d->pipeline == 3) continue;
         const bool raw = false;
-        const int spg = 2;
+        const int spg = (d->input == SDR_IN_F32_REAL) ? 4 : 2;     // real input: four samples per LDS granule
         for (int ri = 0; ri < 4; ++ri) {
             const int R = Rs[ri];
             if (d->outputs_per_lane && d->outputs_per_lane != R) continue;
@@ -1683,7 +1719,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 const int NT = NTs[ni];
                 if (d->threads && d->threads != NT) continue;
                 Geometry gm;
-                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false, d->mix_fr != 0.0)) break;
+                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false, d->mix_fr != 0.0 && spg == 2)) break;
                 if (gm.n_inst > kSlots && pass == 0) continue;
                 const bool forced = d->threads != 0;
                 // automatic choice: float tiles <= 53 KB (3 workgroups per CU)
@@ -1708,7 +1744,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                        d->decim, d->n_taps, d->outputs_per_lane, d->threads, d->pipeline);
         return SDR_EINVAL;
     }
-    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma && !p->mfma_i8; p->spg = best_raw ? 4 : 2;
+    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma && !p->mfma_i8; p->spg = (best_raw || p->input == SDR_IN_F32_REAL) ? 4 : 2;
     p->Tback = best.Tback; p->Lw4 = best.Lw4; p->ngran = best.ngran; p->q = best.q; p->pad = best.pad;
     p->s_gran = best.s_gran; p->a_gran = best.a_gran; p->n_inst = best.n_inst; p->lds_bytes = best.lds_bytes;
     {
@@ -1733,13 +1769,19 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     // gtab[j][r] = h[D*r + Tback - j]  (tap that window offset j contributes to output r);
     // rows past the window (padding + look-ahead step) stay zero
     const size_t rows = (size_t)(best.ngran + best.look) * p->spg;
-    std::vector<float> gt(rows * p->R, 0.0f);
+    const bool real_tile = !p->raw && p->input == SDR_IN_F32_REAL;
+    std::vector<float> gt(rows * p->R * (real_tile ? 2 : 1), 0.0f);
     for (size_t j = 0; j < rows; ++j)
         for (int r = 0; r < p->R; ++r) {
             const long long i = (long long)p->D * r + p->Tback - (long long)j;
-            if (i >= 0 && i < p->T) gt[j * p->R + r] = hf[i];
+            if (i < 0 || i >= p->T) continue;
+            if (!real_tile) { gt[j * p->R + r] = hf[i]; continue; }
+            // complex taps h[i] * exp(-j*2*pi*fr*i), phase reduced in double
+            const double ph = p->mix_fr * (double)i, f = ph - std::rint(ph);
+            gt[2 * (j * p->R + r)] = (float)(d->taps[i] * std::cos(2.0 * M_PI * f));
+            gt[2 * (j * p->R + r) + 1] = (float)(-d->taps[i] * std::sin(2.0 * M_PI * f));
         }
-    if (!p->raw && p->mix_fr != 0.0) {
+    if (!p->raw && p->mix_fr != 0.0 && !real_tile) {
         // mixer phasor tables (see fir_stream_kernel), phases reduced in double
         while (gt.size() % 4) gt.push_back(0.0f);                 // 16-byte aligned
         p->ph_off = (int)gt.size();

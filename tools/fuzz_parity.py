@@ -133,13 +133,15 @@ def one_case(rng, case_seed):
         assert np.all(back[: oo * w] == 0x7FC0DEAD) and np.all(back[(oo + cnt) * w:] == 0x7FC0DEAD), tag + f" wrote outside its outputs (so={so} oo={oo})"
         assert np.array_equal(back[oo * w: (oo + cnt) * w], got.view(np.uint32).reshape(-1)), tag + f" differs at pointer offsets so={so} oo={oo}"
     # a random shard cut of the same stream must reproduce the whole
-    if cnt >= 2 and kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI):
+    int_kind = kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI)
+    per = 2 if kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ) else 1      # array elements per sample
+    if cnt >= 2 and (int_kind or mode != sdr.MODE_FM):
         ob = int(rng.integers(0, cnt - 1))
         oe = int(rng.integers(ob + 1, cnt + 1))
         lo = max(0, ob * D - (T - 1) - int(rng.integers(0, 3)))
         hi = min(n, (oe + 1) * D + 1 + int(rng.integers(0, 3)))
         eb = 8 if mode == sdr.MODE_IQ else 4
-        d_blk = sdr.DevBuf.from_numpy(raw[2 * lo: 2 * hi])
+        d_blk = sdr.DevBuf.from_numpy(raw[per * lo: per * hi])
         d_out = sdr.DevBuf((oe - ob) * eb)
         plan.execute_range_dev(d_blk, lo, hi - lo, n, ob, oe, d_out)
         sdr.sync()

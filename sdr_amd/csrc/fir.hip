@@ -1732,6 +1732,11 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 if (gm.pad) cost *= 1.1;                                       // padded image: extra index work
                 if (ni > 0) cost *= 1.05;                                      // smaller tiles: more halo
                 if (R == 8) cost *= 2.0;
+                // Tiles with more granules per lane than the small prefetch set go to the 32-slot
+                // instantiation, which stages all 32 slots whatever the tile needs and leaves two
+                // workgroups per CU: measured 1.6-2.7x slower than the best small-set geometry of
+                // the same shape (complex float input, T = 64..511, D = 3..20), so it is a last resort
+                if (gm.n_inst > (spg == 4 ? kSlotsReal : kSlotsSmall)) cost *= 2.0;
                 if (gm.n_inst > kSlots) cost *= 1.0 + 0.05 * (gm.n_inst - kSlots);   // unprefetched rest of the tile
                 if (!bestR || cost < best_cost) { best = gm; bestR = R; bestNT = NT; best_raw = raw; best_cost = cost; }
                 break;

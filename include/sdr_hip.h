@@ -112,7 +112,10 @@ typedef struct sdr_fir_desc {
                            T + 63*D (*2 for odd D) samples has to fit the 160 KB of LDS: float
                            input or the mixer (8 B per sample) at 16384 taps stops near D = 30 for
                            odd D, SDR_EINVAL beyond */
-    const double *taps; /* host, T doubles (rounded to float32 on upload; pipeline 5: to 31-bit fixed point) */
+    const double *taps; /* host, T doubles (rounded to float32 on upload; pipeline 5: to 31-bit fixed
+                           point).  Sums are accumulated in float32: <= 4e-7 of full scale at the
+                           reference's filter lengths (64..511 taps), growing like sqrt(T) to about
+                           1e-5 at 16384 taps */
     double scale;       /* FM: discriminator scale, e.g. 1/(2*pi) (bladerf_apt_demod.cpp:560) */
     double mix_fr;      /* != 0: multiply x[n] by exp(+j*2*pi*mix_fr*n) before the FIR
                            (frequency_shift, bladerf_apt_demod.cpp:476-495; sign as

@@ -1465,10 +1465,10 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu); \
         fir_stream_kernel<INK, R, SL><<<nb, p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, g); \
     } while (0)
-    const bool small = p->n_inst <= kSlotsSmall;
-    if (p->input == SDR_IN_I16_IQ || p->input == SDR_IN_I16_QI) { if (small) SDR_STREAM(IN_I16, kSlotsSmall); else SDR_STREAM(IN_I16, kSlots); }
-    else if (p->input == SDR_IN_I8_IQ) { if (small) SDR_STREAM(IN_I8, kSlotsSmall); else SDR_STREAM(IN_I8, kSlots); }
-    else if (p->input == SDR_IN_CF32) { if (small) SDR_STREAM(IN_CF32, kSlotsSmall); else SDR_STREAM(IN_CF32, kSlots); }
+    const bool small = p->n_inst <= kSlotsSmall, mid = p->n_inst <= kSlotsReal;
+    if (p->input == SDR_IN_I16_IQ || p->input == SDR_IN_I16_QI) { if (small) SDR_STREAM(IN_I16, kSlotsSmall); else if (mid) SDR_STREAM(IN_I16, kSlotsReal); else SDR_STREAM(IN_I16, kSlots); }
+    else if (p->input == SDR_IN_I8_IQ) { if (small) SDR_STREAM(IN_I8, kSlotsSmall); else if (mid) SDR_STREAM(IN_I8, kSlotsReal); else SDR_STREAM(IN_I8, kSlots); }
+    else if (p->input == SDR_IN_CF32) { if (small) SDR_STREAM(IN_CF32, kSlotsSmall); else if (mid) SDR_STREAM(IN_CF32, kSlotsReal); else SDR_STREAM(IN_CF32, kSlots); }
     else { if (p->n_inst <= kSlotsReal) SDR_STREAM(IN_REAL, kSlotsReal); else SDR_STREAM(IN_REAL, kSlots); }
 #undef SDR_STREAM
     return hipGetLastError();
@@ -1722,21 +1722,23 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false, d->mix_fr != 0.0 && spg == 2)) break;
                 if (gm.n_inst > kSlots && pass == 0) continue;
                 const bool forced = d->threads != 0;
-                // automatic choice: float tiles <= 53 KB (3 workgroups per CU)
-                const int budget = (forced || ni == 2 || pass == 1) ? 160 * 1024 : 53 * 1024;
+                // automatic choice: float tiles <= 80 KB (two workgroups per CU; three below 53 KB)
+                const int budget = (forced || ni == 2 || pass == 1) ? 160 * 1024 : 80 * 1024;
                 if (gm.lds_bytes > budget) continue;
                 // SIMD cycles per output: one packed FMA per (sample, output), one ds_read_b128
                 // per granule
                 const double walked = (double)gm.ngran * spg;                  // samples per lane
-                double cost = walked * 4.0 + walked / spg * 4.0 / R;
+                double cost = walked * 4.0 + walked / spg * 8.0 / R;         // a 16-byte LDS read per wave: 8 cycles of a pipe four SIMDs share
                 if (gm.pad) cost *= 1.1;                                       // padded image: extra index work
                 if (ni > 0) cost *= 1.05;                                      // smaller tiles: more halo
                 if (R == 8) cost *= 2.0;
-                // Tiles with more granules per lane than the small prefetch set go to the 32-slot
-                // instantiation, which stages all 32 slots whatever the tile needs and leaves two
-                // workgroups per CU: measured 1.6-2.7x slower than the best small-set geometry of
-                // the same shape (complex float input, T = 64..511, D = 3..20), so it is a last resort
-                if (gm.n_inst > (spg == 4 ? kSlotsReal : kSlotsSmall)) cost *= 2.0;
+                // Tiles with more than 20 granules per lane go to the 32-slot instantiation, whose
+                // prefetch set (128 VGPRs for complex float input) spills: measured 1.6-2.7x slower
+                // than the best 12- or 20-slot geometry of the same shape (complex float input,
+                // T = 64..511, D = 3..20; tools/sweep_float_tiles.py), so it is a last resort.
+                // Two workgroups per CU instead of three cost little on long filters.
+                if (gm.n_inst > kSlotsReal) cost *= 2.0;
+                if (gm.lds_bytes > 53 * 1024) cost *= 1.08;
                 if (gm.n_inst > kSlots) cost *= 1.0 + 0.05 * (gm.n_inst - kSlots);   // unprefetched rest of the tile
                 if (!bestR || cost < best_cost) { best = gm; bestR = R; bestNT = NT; best_raw = raw; best_cost = cost; }
                 break;

@@ -10,7 +10,7 @@ n = 1 << 24
 rng = np.random.default_rng(1)
 buf = sdr.DevBuf.from_numpy((rng.standard_normal(2 * n) * 0.3).astype(np.float32))
 d_out = sdr.DevBuf(n * 8 + 64)
-for (T, D) in ((511, 10), (300, 10), (200, 10), (128, 10), (64, 10), (200, 8), (164, 6), (101, 5), (300, 4), (511, 20), (255, 3)):
+for (T, D) in ((511, 15), (511, 20), (200, 15), (101, 20), (300, 13), (511, 10), (300, 10), (200, 10), (128, 10), (64, 10), (64, 20), (32, 16), (200, 8), (164, 6), (101, 5), (300, 4), (255, 3), (64, 2)):
     h = sdr.create_fir_filter(T, 1.0 / D, "hann")
     row = []
     for R in (1, 2, 4):

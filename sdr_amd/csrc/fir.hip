@@ -1730,7 +1730,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 const double walked = (double)gm.ngran * spg;                  // samples per lane
                 double cost = walked * 4.0 + walked / spg * 8.0 / R;         // a 16-byte LDS read per wave: 8 cycles of a pipe four SIMDs share
                 if (gm.pad) cost *= 1.1;                                       // padded image: extra index work
-                if (ni > 0) cost *= 1.05;                                      // smaller tiles: more halo
+                // smaller tiles re-read more halo; real tiles (half the bytes per sample) run best
+                // from 64-lane workgroups all the same (nine of twelve swept shapes, up to 25 %)
+                if (spg == 4 ? ni != 2 : ni > 0) cost *= 1.05;
                 if (R == 8) cost *= 2.0;
                 // Tiles with more than 20 granules per lane go to the 32-slot instantiation, whose
                 // prefetch set (128 VGPRs for complex float input) spills: measured 1.6-2.7x slower
@@ -1741,7 +1743,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 if (gm.lds_bytes > 53 * 1024) cost *= 1.08;
                 if (gm.n_inst > kSlots) cost *= 1.0 + 0.05 * (gm.n_inst - kSlots);   // unprefetched rest of the tile
                 if (!bestR || cost < best_cost) { best = gm; bestR = R; bestNT = NT; best_raw = raw; best_cost = cost; }
-                break;
+                if (spg != 4) break;          // complex tiles: the largest workgroup that fits; real tiles: compare all
             }
         }
     }

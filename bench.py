@@ -43,6 +43,14 @@ def parse():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--config", choices=["stream", "channels"], default="stream",
+                    help="stream (default): BASELINE configs[1], one long stream, time-block shards, weak scaling; "
+                         "channels: BASELINE configs[2], --channels independent channels of 2^--chan-log2n samples "
+                         "block-partitioned over the ranks (strong scaling), one batched launch per rank")
+    ap.add_argument("--channels", type=int, default=1024)
+    ap.add_argument("--chan-log2n", type=int, default=20)
+    ap.add_argument("--prewarm-seconds", type=float, default=2.0,
+                    help="upper bound of the clock-stabilising pre-warm that runs before --warmup (0 = off)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU: every rank uses device 0 and the collectives go "
                          "over gloo on host tensors (checks the sharded path; the numbers mean nothing)")
@@ -126,31 +134,79 @@ def main():
     sdr_amd.init(local)
 
     D, T = a.decim, a.taps
-    n_blk = 1 << a.log2n                       # samples per GPU
-    n_total = n_blk * world
     taps = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")     # cutoff at the decimated Nyquist
     plan = sdr_amd.FirPlan(taps, D, mode=sdr_amd.MODE_FM, scale=1.0 / (2.0 * np.pi),
                            outputs_per_lane=a.outputs_per_lane, threads=a.threads,
                            pipeline=a.pipeline)
     from sdr_amd import shard
-    shards = shard.plan_time_shards(n_total, D, T, shard.MODE_FM, world)
-    me = shards[rank]                          # this rank's slice of the final output
-    cnt_total = plan.out_count(n_total)
-    assert shards[-1].out_end == cnt_total
-    ob, oe = me.out_begin, me.out_end
-    lo, hi = me.lo, me.hi                      # resident window = own block + FIR history halo
-    n_res = hi - lo
-
     st = torch.cuda.current_stream().cuda_stream
-    d_in = torch.empty(2 * n_res + 8, dtype=torch.int16, device=dev)
-    d_out = torch.empty(oe - ob + (T + 2 * D) // D + 64, dtype=torch.float32, device=dev)
-    sdr_amd.capi.synth_fm_i16_dev(d_in, n_res, n0=lo, fs=20.0e6, ftone=1000.0, dev=5000.0,
-                                  amp=2000.0, noise_lsb=0, seed=1, stream=st)
-    torch.cuda.synchronize()
+    channels = a.config == "channels"
+    if channels:
+        # BASELINE configs[2]: independent channels, channel-major; rank r owns a contiguous block of
+        # channels (shard.plan_channel_shards) and filters them in ONE batched launch
+        n_chan = 1 << a.chan_log2n
+        c_first, c_mine = shard.plan_channel_shards(a.channels, world)[rank]
+        cnt_ch = plan.out_count(n_chan)
+        n_blk = c_mine * n_chan                    # samples this rank processes per step
+        n_all = a.channels * n_chan                # samples the whole job processes per step
+        d_in = torch.empty(2 * max(n_blk, 1) + 8, dtype=torch.int16, device=dev)
+        d_out = torch.empty(max(c_mine * cnt_ch, 1) + 64, dtype=torch.float32, device=dev)
+        for c in range(c_mine):                    # per-channel tone 300..3000 Hz, seed = base + channel
+            gc = c_first + c
+            sdr_amd.capi.synth_fm_i16_dev(d_in[2 * c * n_chan:], n_chan, fs=1.0e6,
+                                          ftone=300.0 + 2700.0 * gc / max(a.channels - 1, 1), dev=5000.0,
+                                          noise_lsb=2, seed=100 + gc, stream=st)
+        torch.cuda.synchronize()
 
-    def step():
-        plan.execute_range_dev(d_in, lo, n_res, n_total, ob, oe, d_out, stream=st)
+        def step():
+            if c_mine:
+                plan.execute_batched_dev(d_in, n_chan, n_chan, c_mine, d_out, cnt_ch, stream=st)
+    else:
+        n_blk = 1 << a.log2n                       # samples per GPU
+        n_total = n_blk * world
+        n_all = n_total
+        shards = shard.plan_time_shards(n_total, D, T, shard.MODE_FM, world)
+        me = shards[rank]                          # this rank's slice of the final output
+        cnt_total = plan.out_count(n_total)
+        assert shards[-1].out_end == cnt_total
+        ob, oe = me.out_begin, me.out_end
+        lo, hi = me.lo, me.hi                      # resident window = own block + FIR history halo
+        n_res = hi - lo
 
+        d_in = torch.empty(2 * n_res + 8, dtype=torch.int16, device=dev)
+        d_out = torch.empty(oe - ob + (T + 2 * D) // D + 64, dtype=torch.float32, device=dev)
+        sdr_amd.capi.synth_fm_i16_dev(d_in, n_res, n0=lo, fs=20.0e6, ftone=1000.0, dev=5000.0,
+                                      amp=2000.0, noise_lsb=0, seed=1, stream=st)
+        torch.cuda.synchronize()
+
+        def step():
+            plan.execute_range_dev(d_in, lo, n_res, n_total, ob, oe, d_out, stream=st)
+
+    # Clock-stabilising pre-warm, independent of --warmup: the first launches after idle run 10-15 %
+    # slow (clock ramp), so batches of launches are event-timed until two consecutive batches agree
+    # within 1 %, bounded by --prewarm-seconds.  Untimed: nothing of it enters `value`.
+    prewarm = {"launches": 0, "batches": 0, "ms_last_batch": None, "stable": False, "wall_s": 0.0}
+    if a.prewarm_seconds > 0:
+        pw0 = time.perf_counter()
+        prev = None
+        batch = 20
+        while time.perf_counter() - pw0 < a.prewarm_seconds:
+            b0 = torch.cuda.Event(enable_timing=True)
+            b1 = torch.cuda.Event(enable_timing=True)
+            b0.record()
+            for _ in range(batch):
+                step()
+            b1.record()
+            b1.synchronize()
+            cur = b0.elapsed_time(b1) / batch
+            prewarm["launches"] += batch
+            prewarm["batches"] += 1
+            prewarm["ms_last_batch"] = round(cur, 4)
+            if prev is not None and prewarm["batches"] >= 3 and abs(cur - prev) <= 0.01 * cur:
+                prewarm["stable"] = True
+                break
+            prev = cur
+        prewarm["wall_s"] = round(time.perf_counter() - pw0, 3)
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -158,13 +214,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     # HIP events on the launch stream (st IS torch's current stream) bracket the same K launches
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    # (one event per step as well: min / median over the timed steps)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    ev0, ev1 = evs[0], evs[-1]
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         step()
-    ev1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -178,13 +235,24 @@ def main():
     # ---- kernel time (roofline): the K launches of the timed region, back to back on one stream,
     # between the two HIP events; each launch processes this rank's n_blk samples
     ms_kernel = ev0.elapsed_time(ev1) / a.steps
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+    ms_min, ms_med = per_step[0], per_step[len(per_step) // 2]
     n_kernel = n_blk
     bytes_per_sample = 4.0 + 4.0 / D
     achieved = bytes_per_sample * n_kernel / (ms_kernel * 1e-3) / 1e9
 
     # ---- spot parity at full size: three slices (start, past 2^31 bytes, end) vs the oracle --
     parity = None
-    if rank == 0:
+    if rank == 0 and channels:
+        worst = 0.0
+        for c in sorted({0, c_mine // 2, c_mine - 1}) if c_mine else []:
+            blk = d_in[2 * c * n_chan: 2 * (c + 1) * n_chan].cpu().numpy()
+            want = O.chain_i16(blk, D, taps, O.MODE_FM, 1.0 / (2.0 * np.pi))
+            got = d_out[c * cnt_ch: (c + 1) * cnt_ch].cpu().numpy().astype(np.float64)
+            worst = max(worst, float(np.abs(got - want).max()))
+        parity = worst
+        assert worst <= 1e-5 * 0.5, f"full-size parity failed: {worst}"
+    elif rank == 0:
         worst = 0.0
         out_n = oe - ob
         for j0 in (0, out_n // 2 + 12345, out_n - 4096):
@@ -203,7 +271,9 @@ def main():
     gather_ms = gather_error = None
     if dist and not a.no_gather:
         # final collection of the decimated output on rank 0 over xGMI (RCCL gather), once per job
-        counts = [sh.n_out for sh in shards]
+        counts = [k * cnt_ch for (_c0, k) in shard.plan_channel_shards(a.channels, world)] if channels \
+            else [sh.n_out for sh in shards]
+        cnt_total = sum(counts)
         torch.cuda.synchronize(); dist.barrier()
         g0 = time.perf_counter()
         try:
@@ -215,7 +285,21 @@ def main():
             print(f"rank {rank}: final gather failed: {gather_error}", file=sys.stderr)
         if rank == 0 and gathered is not None:
             assert gathered.numel() == cnt_total
-            if a.rehearse:
+            if a.rehearse and channels:
+                # the gathered channel blocks must equal all channels filtered in one launch, bit for bit
+                d_all = torch.empty(2 * n_all + 8, dtype=torch.int16, device=dev)
+                for gc in range(a.channels):
+                    sdr_amd.capi.synth_fm_i16_dev(d_all[2 * gc * n_chan:], n_chan, fs=1.0e6,
+                                                  ftone=300.0 + 2700.0 * gc / max(a.channels - 1, 1), dev=5000.0,
+                                                  noise_lsb=2, seed=100 + gc, stream=st)
+                d_one = torch.empty(cnt_total + 8, dtype=torch.float32, device=dev)
+                plan.execute_batched_dev(d_all, n_chan, n_chan, a.channels, d_one, cnt_ch, stream=st)
+                torch.cuda.synchronize()
+                n_bad = int((gathered != d_one[:cnt_total].cpu()).sum())
+                assert n_bad == 0, n_bad
+                print(f"rehearsal: gathered channel blocks vs one launch over all {a.channels} channels: "
+                      f"{cnt_total} outputs, {n_bad} differ", file=sys.stderr)
+            elif a.rehearse:
                 # the gathered shards must equal the whole stream filtered in one piece, bit for bit
                 d_all = torch.empty(2 * n_total + 8, dtype=torch.int16, device=dev)
                 sdr_amd.capi.synth_fm_i16_dev(d_all, n_total, n0=0, fs=20.0e6, ftone=1000.0, dev=5000.0,
@@ -234,35 +318,53 @@ def main():
 
     # the same launch once more in the library's own event loop, after everything is warm (last:
     # it treats the resident window as a stream of its own and overwrites d_out)
-    ms_warm = plan.time_dev(d_in, n_res if world > 1 else n_blk, d_out, max(5, a.steps), stream=st)
+    if channels:
+        ms_warm = plan.time_dev(d_in, n_chan, d_out, max(5, a.steps), in_stride=n_chan, n_channels=max(c_mine, 1),
+                                out_stride=cnt_ch, stream=st)
+    else:
+        ms_warm = plan.time_dev(d_in, n_res if world > 1 else n_blk, d_out, max(5, a.steps), stream=st)
 
     if rank == 0:
-        value = n_blk * world * a.steps / dt / 1e6
+        value = n_all * a.steps / dt / 1e6
         info = plan.info()
-        traffic = None
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process (they
+        # need rocprofv3 around it): the figure comes from the tracked summary of the last counter run
+        # of this same command and is labelled with its source
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("fir_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("fir_bytes_per_launch")
+                traffic_source = "profiles/hbm_traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, not this run")
             except Exception:
                 traffic = None
         line = {
             "metric": "input Msamples/s through FIR-decimate+FM demod",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"FM chain, single 20 MSps stream, 2^{a.log2n}-sample int16 IQ block per GPU, "
-                                   f"{T}-tap Hann LPF, decimate by {D}, discriminator (BASELINE configs[1])",
-                       "samples_per_gpu": n_blk, "taps": T, "decim": D,
-                       "sharding": "time blocks with FIR history halo" if world > 1 else "none",
-                       "kernel": info},
+            "higher_is_better": True, "scaling": "strong" if channels else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": ({"workload": f"FM channelizer, {a.channels} independent channels x 2^{a.chan_log2n} int16 IQ samples, "
+                                    f"{T}-tap Hann LPF, decimate by {D}, discriminator (BASELINE configs[2]); "
+                                    f"channels block-partitioned over the ranks, one batched launch per rank",
+                        "channels": a.channels, "samples_per_channel": n_chan, "channels_rank0": c_mine,
+                        "taps": T, "decim": D, "sharding": "channel blocks" if world > 1 else "none", "kernel": info}
+                       if channels else
+                       {"workload": f"FM chain, single 20 MSps stream, 2^{a.log2n}-sample int16 IQ block per GPU, "
+                                    f"{T}-tap Hann LPF, decimate by {D}, discriminator (BASELINE configs[1])",
+                        "samples_per_gpu": n_blk, "taps": T, "decim": D,
+                        "sharding": "time blocks with FIR history halo" if world > 1 else "none",
+                        "kernel": info}),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel_ms": round(ms_kernel, 4),
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": round(ms_kernel, 4),
+                         "kernel_ms_min": round(ms_min, 4), "kernel_ms_median": round(ms_med, 4),
                          "kernel_ms_after_timed_region": round(ms_warm, 4),
                          "algorithmic_bytes_per_sample": bytes_per_sample},
             "parity_max_abs_err": parity,
+            "prewarm": prewarm,
         }
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)

@@ -49,7 +49,32 @@ enum sdr_status {
     SDR_ERANGE = 7      /* requested samples are outside the resident window */
 };
 
-/* output of the FIR-decimate chain */
+/* output of the FIR-decimate chain
+ *
+ * Accuracy of the float32 outputs against the float64 reference arithmetic (BASELINE north_star:
+ * "<= 1e-5 of full scale"), as the GPU tests hold it (tests/test_gpu_parity.py check_linear / check_fm,
+ * tools/fuzz_parity.py):
+ *   IQ, ENV, REAL  |err| <= e = 1e-5 * FS, FS = max(1, max|y|) (Q11 full scale is 1.0).  No exemption.
+ *   FM             full scale is scale*pi (0.5 for scale 1/(2*pi)); outputs compare modulo one turn.
+ *                  The output is the ANGLE of y[m+1]*conj(y[m]), so the linear bound e on y turns into
+ *                  scale*(e/|y[m]| + e/|y[m+1]|) on the angle.  That is within 1e-5 of full scale wherever
+ *                  both |y| exceed 1e-3 of the block's rms, and the tests demand 1e-5 there.  Three
+ *                  documented exemptions, all "the angle of a (nearly) zero vector":
+ *                  (1) ill-conditioned angles: where |y[m]| or |y[m+1]| is below 1e-3 of the block rms
+ *                      the bound is the one above (the tests allow 1e-3 of full scale); any float32
+ *                      evaluation, the reference's own ArrayFire path included, moves these outputs;
+ *                  (2) start-up transient: the first ceil((T-1)/D)+1 outputs of a stream come from
+ *                      partly filled windows (zero pre-history, bladerf_apt_demod.cpp:299-305) and are
+ *                      small, so rule (1) usually applies to them; nothing else is special about them.
+ *                      Where y[m] is EXACTLY zero the reference's 0 / +-pi (from the signs of its zeros,
+ *                      bladerf_apt_demod.cpp:419-421) is reproduced bit for bit by every kernel;
+ *                  (3) pipeline 5 only: taps below 2^-31 of the largest tap vanish in its fixed point.
+ *                      After a run of >= T zero samples in mid-stream, the first output whose window
+ *                      meets a non-zero sample ONLY through such taps has y == 0 here and a tiny y in
+ *                      the reference: that output and its predecessor report the angle of a zero vector
+ *                      (0 or +-scale*pi) instead of the reference's.  At a stream's start the same
+ *                      situation is repaired (recomputed with float32 taps); in mid-stream it is not.
+ *                      Pinned by tests/test_gpu_parity.py::test_pipeline5_zero_run_deviation. */
 enum sdr_mode {
     SDR_MODE_IQ = 0,    /* complex y[m] (float2)           -- polyphase_decimate alone        */
     SDR_MODE_FM = 1,    /* scale*arg(y[m+1] conj(y[m]))    -- + polar_discriminator           */
@@ -71,6 +96,17 @@ enum sdr_input {
                            in hackrf/tx_example/src/hackrf_tx_main.cpp:150-151); scale 1/128        */
 };
 
+/* how many decimated samples y[m] = (h * x)[D*m] a block of n_in input samples yields */
+enum sdr_count_rule {
+    SDR_COUNT_FLOOR = 0,  /* m < floor(n_in/D): polyphase_decimate, bladerf_apt_demod.cpp:282 (APT chain) */
+    SDR_COUNT_AF_SEQ = 1  /* D*m <= n_in-1, i.e. floor((n_in-1)/D)+1 samples: the ArrayFire loops'
+                             x3(dec_seq), dec_seq = af::seq(0, num_samples, dec_rate) (inclusive end;
+                             bladerf_fm_demod.cpp:212,227,294,307, bladerf_am_demod.cpp:213,297).  One
+                             sample more than FLOOR unless D divides n_in -- then the seq's last index
+                             IS n_in, one past the block (a latent out-of-bounds read in the reference,
+                             SURVEY 8 a4): that index is never read here and the count stays n_in/D */
+};
+
 enum sdr_window_id {
     SDR_WIN_RECTANGULAR = 0, SDR_WIN_HANN = 1, SDR_WIN_HAMMING = 2, SDR_WIN_BLACKMAN = 3,
     SDR_WIN_NUTTALL = 4, SDR_WIN_BLACKMAN_HARRIS = 5
@@ -84,6 +120,11 @@ typedef struct sdr_fft_plan sdr_fft_plan;
 /* Select `device` (HIP ordinal) for the calling thread and check that it is gfx950.
  * No reference counterpart (the reference is CPU-only). */
 int sdr_init(int device);
+/* "libsdrhip product build (gfx950)", or a text that starts with "libsdrhip MEASUREMENT BUILD" when
+ * a translation unit was compiled with -DSDR_MEASUREMENT_BUILD (kernel parts compiled out to time the
+ * rest: wrong results by construction; sdr_init() then prints this text to stderr).  The build of
+ * sdr_amd/capi.py / __graft_entry__.build() never sets it. */
+const char *sdr_build_info(void);
 const char *sdr_strerror(int status);
 /* text of the last failure on the calling thread (HIP error string, argument name...) */
 const char *sdr_last_error(void);
@@ -133,20 +174,22 @@ typedef struct sdr_fir_desc {
                              matrix cores in float32 (long filters; int16 without mixer only);
                              5 = Toeplitz GEMM on the int8 matrix pipe: samples as their two
                              bytes, taps as four base-256 digits, exact int32 accumulation
-                             (windows T + 15*D up to 768 samples; int16 without mixer only;
-                             leave outputs_per_lane and threads 0).  Chosen automatically where a
+                             (windows T + 15*D up to 768 samples; at least 2 taps; int16 without
+                             mixer only; leave outputs_per_lane and threads 0).  Chosen automatically where a
                              measured cost model (tiles vs taps per sample) puts it ahead.  Taps
                              smaller than 2^-31 of the largest one are dropped by the fixed point;
                              the discriminator outputs of a stream's start-up transient, where
                              such taps can decide the angle, are recomputed with float32 taps. */
+    int count_rule;       /* enum sdr_count_rule; 0 = the polyphase_decimate rule */
 } sdr_fir_desc;
 
 /* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument
  * checks + polyphase table) and af::array(lpf) (bladerf_fm_demod.cpp:217). */
 int sdr_fir_plan_create(const sdr_fir_desc *desc, sdr_fir_plan **plan);
 int sdr_fir_plan_destroy(sdr_fir_plan *plan);
-/* number of outputs for n_in input samples: floor(n_in/D) (bladerf_apt_demod.cpp:282), minus
- * one in FM mode (:409). */
+/* number of outputs for n_in input samples: floor(n_in/D) (bladerf_apt_demod.cpp:282) or, for plans
+ * with SDR_COUNT_AF_SEQ, floor((n_in-1)/D)+1; minus one in FM mode (:409; x4(1:end) * conjg(x4(0:end-1)),
+ * bladerf_fm_demod.cpp:297). */
 size_t sdr_fir_out_count(const sdr_fir_plan *plan, size_t n_in);
 /* what the plan chose: outputs per lane, threads per workgroup, LDS bytes per workgroup */
 int sdr_fir_plan_info(const sdr_fir_plan *plan, int *outputs_per_lane, int *threads,

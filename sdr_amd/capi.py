@@ -17,6 +17,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 OK, EINVAL, ENOMEM, EHIP, EALIGN, ECAPACITY, ENODEV, ERANGE = range(8)
 MODE_IQ, MODE_FM, MODE_ENV, MODE_REAL = 0, 1, 2, 3
+COUNT_FLOOR, COUNT_AF_SEQ = 0, 1
 IN_I16_IQ, IN_CF32, IN_F32_REAL, IN_I16_QI, IN_I8_IQ = 0, 1, 2, 3, 4
 WINDOWS = {"rectangular": 0, "hann": 1, "hamming": 2, "blackman": 3, "nuttall": 4,
            "blackman_harris": 5}
@@ -31,7 +32,8 @@ class SdrError(RuntimeError):
 class FirDesc(C.Structure):
     _fields_ = [("input", C.c_int), ("mode", C.c_int), ("decim", C.c_int), ("n_taps", C.c_int),
                 ("taps", C.POINTER(C.c_double)), ("scale", C.c_double), ("mix_fr", C.c_double),
-                ("outputs_per_lane", C.c_int), ("threads", C.c_int), ("pipeline", C.c_int)]
+                ("outputs_per_lane", C.c_int), ("threads", C.c_int), ("pipeline", C.c_int),
+                ("count_rule", C.c_int)]
 
 
 # per-file compiler flags: the FFT's complex butterflies lose ~12 % when the SLP vectoriser pairs
@@ -76,6 +78,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.sdr_strerror.restype = C.c_char_p
         L.sdr_last_error.restype = C.c_char_p
+        L.sdr_build_info.restype = C.c_char_p
         L.sdr_fir_out_count.restype = C.c_size_t
         L.sdr_fir_out_count.argtypes = [C.c_void_p, C.c_size_t]
         L.sdr_fft_frame_count.restype = C.c_size_t
@@ -92,6 +95,10 @@ def check(status):
 
 def init(device=0):
     check(lib().sdr_init(C.c_int(device)))
+
+
+def build_info():
+    return lib().sdr_build_info().decode()
 
 
 # ------------------------------------------------------------------------------ host design --
@@ -170,12 +177,12 @@ class FirPlan:
     """sdr_fir_plan: FIR + decimate (+ mixer) + {IQ, FM discriminator, envelope}."""
 
     def __init__(self, taps, decim, mode=MODE_FM, input=IN_I16_IQ, scale=1.0 / (2.0 * np.pi),
-                 mix_fr=0.0, outputs_per_lane=0, threads=0, pipeline=0):
+                 mix_fr=0.0, outputs_per_lane=0, threads=0, pipeline=0, count_rule=COUNT_FLOOR):
         self._taps = np.ascontiguousarray(taps, dtype=np.float64)
         self.mode, self.input, self.decim = mode, input, decim
         d = FirDesc(input, mode, decim, self._taps.size,
                     self._taps.ctypes.data_as(C.POINTER(C.c_double)), scale, mix_fr,
-                    outputs_per_lane, threads, pipeline)
+                    outputs_per_lane, threads, pipeline, count_rule)
         self.h = C.c_void_p()
         check(lib().sdr_fir_plan_create(C.byref(d), C.byref(self.h)))
 

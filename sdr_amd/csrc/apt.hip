@@ -70,7 +70,15 @@ extern "C" int sdr_apt_image_push(sdr_apt_image *a, const float *x9, size_t n, i
         if (a->x10[i] > x_max) x_max = a->x10[i];
     }
     const double delta = x_max - x_min;
-    if (!(delta > 0.0)) return SDR_OK;    // constant block: the reference divides by zero
+    if (!(delta > 0.0)) {
+        // constant backlog (squelched or zero input): the reference divides by zero here.  No line can
+        // be found in it, so keep what a later line could still start in -- the last width + 500
+        // samples, the same margin the drop rule below leaves -- and let the rest go: the state stays
+        // bounded however long the input stays constant
+        const size_t keep = (size_t)a->width + (size_t)kSkip;
+        if (N > keep) a->x10.erase(a->x10.begin(), a->x10.begin() + (N - keep));
+        return SDR_OK;
+    }
     const double alpha = 255.0 / delta, beta = -x_min * alpha;                  // :766
     std::vector<int16_t> x12(N);
     std::vector<uint8_t> x11u(N);

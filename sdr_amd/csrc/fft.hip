@@ -146,7 +146,7 @@ __device__ __forceinline__ void dft<16>(cf (&x)[16])
 
 __device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
 
-// Measurement builds only (tools/fft_ablate.sh; the results are wrong by construction):
+// SDR_MEASUREMENT_BUILD only (sdr_internal.h; tools/fft_ablate.sh; the results are wrong by construction):
 // bit 0 = no LDS exchanges (later passes take the lane's own registers), bit 1 = no butterflies,
 // bit 2 = no log, bit 3 = every workgroup stores to one row of its own (the stores stay in L2), bit 4 = the
 // sample loads read one cached row.  The shipped library is built with 0.
@@ -548,6 +548,14 @@ fft_big_pass_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ w
 }
 
 }  // namespace
+
+namespace sdr {
+#ifdef SDR_MEASUREMENT_BUILD
+int measurement_flags_fft() { return SDR_FFT_ABLATE ? SDR_FFT_ABLATE : -1; }
+#else
+int measurement_flags_fft() { return 0; }
+#endif
+}  // namespace sdr
 
 struct sdr_fft_plan {
     int nfft, hop;

@@ -40,6 +40,7 @@
 // reference.  For int16 input the exact 2^-11 Q11 scale is folded into the
 // taps.
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -1002,10 +1003,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kI8Steps = 3;        // k steps per matrix wave (12 steps of 64 = windows up to 768 samples)
 // octets (8 samples) a staging lane fetches ahead per tile: 4 (6 for the 1024-output tile) x 256 x 8 samples
 
+// SDR_MEASUREMENT_BUILD only (sdr_internal.h): 1 no k loop, 2 no staging, 4 no epilogue
 #ifdef SDR_I8_ABLATE
 #define SDR_I8_ABL SDR_I8_ABLATE
 #else
-#define SDR_I8_ABL 0               // measurement builds: 1 no k loop, 2 no staging, 4 no epilogue
+#define SDR_I8_ABL 0
 #endif
 
 __device__ __forceinline__ i32x4 as_i32x4(uint4 v) { return __builtin_bit_cast(i32x4, v); }
@@ -1338,11 +1340,20 @@ fir_startup_fm_kernel(const uint32_t *__restrict__ in, float *__restrict__ out,
 
 }  // namespace
 
+namespace sdr {
+#ifdef SDR_MEASUREMENT_BUILD
+int measurement_flags_fir() { return SDR_I8_ABL ? SDR_I8_ABL : -1; }
+#else
+int measurement_flags_fir() { return 0; }
+#endif
+}  // namespace sdr
+
 // =============================================================================================
 // host side
 // =============================================================================================
 struct sdr_fir_plan {
     int input, mode, D, T, R, NT;
+    int count_rule = SDR_COUNT_FLOOR;   // sdr_count_rule
     bool raw;               // raw-tile geometry (4 samples per granule): fir_raw_kernel or fir_planar_kernel
     bool planar = false;    // fir_planar_kernel (float planes, convert once)
     bool mfma = false;      // fir_mfma_kernel (float planes, Toeplitz GEMM on the matrix cores)
@@ -1364,7 +1375,9 @@ struct sdr_fir_plan {
     void *d_in = nullptr, *d_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
     int device = 0;
-    mutable bool lds_opt_in = false;   // the kernel's dynamic LDS limit has been raised (once per plan)
+    // the kernel's dynamic LDS limit has been raised (set after the first successful launch; execute
+    // calls of one plan may run on several threads, and a repeated opt-in is harmless)
+    mutable std::atomic<bool> lds_opt_in{false};
 };
 
 namespace {
@@ -1411,17 +1424,28 @@ bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *
 size_t in_elem_bytes(int input) { return sdr::in_elem_bytes(input); }
 size_t out_elem_bytes(int mode) { return mode == SDR_MODE_IQ ? 8 : 4; }
 
+// Raise the kernel's dynamic LDS limit when the plan's tile needs more than the default 64 KB (once
+// per plan; the flag is set only after a successful opt-in and launch).  A failure is reported by
+// name instead of surfacing as a generic launch error.
+#define SDR_OPT_IN(...)                                                                          \
+    do {                                                                                         \
+        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in.load(std::memory_order_relaxed)) {        \
+            const hipError_t ea_ = hipFuncSetAttribute((const void *)(__VA_ARGS__),              \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu); \
+            if (ea_ != hipSuccess) { *what = "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"; return ea_; } \
+        }                                                                                        \
+    } while (0)
+
 template <int R>
 hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void *out,
-                    const FirGeom &g, unsigned tiles, unsigned n_ch)
+                    const FirGeom &g, unsigned tiles, unsigned n_ch, const char **what)
 {
+    *what = "fir kernel launch";
     if (p->mfma_i8) {
         const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
 #define SDR_I8(NS, CB)                                                                           \
     do {                                                                                         \
-        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)                                                            \
-            (void)hipFuncSetAttribute((const void *)fir_mfma_i8_kernel<NS, CB>,                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu); \
+        SDR_OPT_IN(fir_mfma_i8_kernel<NS, CB>);                                                  \
         fir_mfma_i8_kernel<NS, CB><<<nb, 1024, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale);                \
     } while (0)
@@ -1434,25 +1458,19 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         return hipGetLastError();
     }
     if (p->mfma) {
-        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)
-            (void)hipFuncSetAttribute((const void *)fir_mfma_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
+        SDR_OPT_IN(fir_mfma_kernel);
         fir_mfma_kernel<<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), 256, p->lds_bytes, st>>>(
             (const uint32_t *)in, out, p->d_atab, g);
         return hipGetLastError();
     }
     if (p->planar) {
-        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)
-            (void)hipFuncSetAttribute((const void *)fir_planar_kernel<R>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
+        SDR_OPT_IN(fir_planar_kernel<R>);
         fir_planar_kernel<R><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
                                                                            p->d_gtab, g);
         return hipGetLastError();
     }
     if (p->raw) {
-        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)
-            (void)hipFuncSetAttribute((const void *)fir_raw_kernel<R>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu);
+        SDR_OPT_IN(fir_raw_kernel<R>);
         fir_raw_kernel<R><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
                                                                         p->d_gtab, g);
         return hipGetLastError();
@@ -1460,9 +1478,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
     const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
 #define SDR_STREAM(INK, SL)                                                                      \
     do {                                                                                         \
-        if (p->lds_bytes > 64 * 1024 && !p->lds_opt_in)                                                            \
-            (void)hipFuncSetAttribute((const void *)fir_stream_kernel<INK, R, SL>,               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu); \
+        SDR_OPT_IN(fir_stream_kernel<INK, R, SL>);                                               \
         fir_stream_kernel<INK, R, SL><<<nb, p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, g); \
     } while (0)
     const bool small = p->n_inst <= kSlotsSmall, mid = p->n_inst <= kSlotsReal;
@@ -1473,6 +1489,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
 #undef SDR_STREAM
     return hipGetLastError();
 }
+#undef SDR_OPT_IN
 
 // Enqueue one launch.  `in` points at stream sample index in_first of channel 0.
 int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resident,
@@ -1518,14 +1535,15 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     // virtual pointer to stream sample 0 of channel 0 (only dereferenced inside the valid window)
     const void *base = (const unsigned char *)in - (size_t)in_first * in_elem_bytes(p->input);
     hipError_t e;
+    const char *what = "fir kernel launch";
     switch (p->R) {
-    case 1: e = launch_r<1>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
-    case 2: e = launch_r<2>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
-    case 4: e = launch_r<4>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
-    default: e = launch_r<8>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch); break;
+    case 1: e = launch_r<1>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch, &what); break;
+    case 2: e = launch_r<2>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch, &what); break;
+    case 4: e = launch_r<4>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch, &what); break;
+    default: e = launch_r<8>(p, st, base, out, g, (unsigned)tiles, (unsigned)n_ch, &what); break;
     }
-    if (e != hipSuccess) return sdr::hip_fail(e, "fir kernel launch");
-    p->lds_opt_in = true;
+    if (e != hipSuccess) return sdr::hip_fail(e, what);
+    p->lds_opt_in.store(true, std::memory_order_relaxed);
     if (p->mfma_i8 && p->d_ftaps && p->mode == SDR_MODE_FM && out_begin * p->D < p->T - 1) {
         // start-up outputs again, with float32 taps (see fir_startup_fm_kernel)
         long long split = (p->T - 1 + p->D - 1) / p->D + 1;
@@ -1541,7 +1559,10 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
 // number of final outputs for a stream of n samples
 long long out_count(const sdr_fir_plan *p, long long n)
 {
-    const long long ny = n / p->D;
+    // y[m] = filtered sample D*m: m < floor(n/D) as polyphase_decimate (bladerf_apt_demod.cpp:282), or
+    // every index 0, D, 2D, ... <= n-1 as x3(af::seq(0, n, D)) picks them (bladerf_fm_demod.cpp:212,294;
+    // the seq's inclusive end n itself is past the block and never read here)
+    const long long ny = (p->count_rule == SDR_COUNT_AF_SEQ) ? (n > 0 ? (n - 1) / p->D + 1 : 0) : n / p->D;
     if (p->mode == SDR_MODE_FM) return ny > 0 ? ny - 1 : 0;
     return ny;
 }
@@ -1559,12 +1580,13 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->input < SDR_IN_I16_IQ || d->input > SDR_IN_I8_IQ) { sdr::set_error("bad input kind"); return SDR_EINVAL; }
     if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_REAL) { sdr::set_error("bad mode"); return SDR_EINVAL; }
     if (d->pipeline < 0 || d->pipeline > 5) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
+    if (d->count_rule != SDR_COUNT_FLOOR && d->count_rule != SDR_COUNT_AF_SEQ) { sdr::set_error("bad count_rule"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
 
     sdr_fir_plan *p = new sdr_fir_plan();
     p->input = d->input; p->mode = d->mode; p->D = d->decim; p->T = d->n_taps;
-    p->scale = d->scale; p->mix_fr = d->mix_fr;
+    p->scale = d->scale; p->mix_fr = d->mix_fr; p->count_rule = d->count_rule;
     (void)hipGetDevice(&p->device);
     const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0);
     if ((d->pipeline == 1 || d->pipeline >= 3) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3, 4 and 5 need int16 input without mixer"); return SDR_EINVAL; }
@@ -1625,6 +1647,13 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
         const double t_i8 = std::fmax(0.26, tiles_per_cu * per_tile_us * 1e-3);
         auto_i8 = t_i8 < 0.9 * t_valu;
+    }
+    if (d->pipeline == 5 && d->n_taps < 2) {
+        // no history halo: a tile at the stream's end could hold fewer than the four valid samples its
+        // 16-byte staging loads need, and a one-tap "filter" has nothing for the matrix pipe anyway
+        delete p;
+        sdr::set_error("pipeline 5 needs at least 2 taps");
+        return SDR_EINVAL;
     }
     if (d->pipeline == 5 || auto_i8) {
         bool fits = true;

@@ -23,6 +23,19 @@ int same_device(int plan_device);   // SDR_OK when the calling thread's current 
         if (e_ != hipSuccess) return ::sdr::hip_fail(e_, #call); \
     } while (0)
 
+// Measurement switches (SDR_I8_ABLATE in fir.hip; SDR_FFT_ABLATE, SDR_FFT_PADLDS, SDR_FFT_MINB in
+// fft.hip) compile parts of a kernel out to time the rest: their results are wrong by construction.
+// They are honoured only under -DSDR_MEASUREMENT_BUILD, which capi.build() never sets, and a
+// library that contains such a translation unit says so: sdr_build_info() names it and sdr_init()
+// prints a warning.
+#ifndef SDR_MEASUREMENT_BUILD
+#if defined(SDR_I8_ABLATE) || defined(SDR_FFT_ABLATE) || defined(SDR_FFT_PADLDS) || defined(SDR_FFT_MINB) || defined(SDR_FFT_NT_MIN)
+#error "kernel ablation switches need -DSDR_MEASUREMENT_BUILD: such a library computes wrong results on purpose"
+#endif
+#endif
+int measurement_flags_fir();  // 0 in the product; the ablation mask of fir.hip in a measurement build (-1: none set)
+int measurement_flags_fft();  // the same for fft.hip
+
 // 2^-11: the Q11 scale of BLADERF_FORMAT_SC16_Q11 samples (bladerf_sdr.h:274)
 constexpr float kQ11 = 1.0f / 2048.0f;
 // 2^-7: full scale of the HackRF's int8 samples

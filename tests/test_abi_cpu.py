@@ -70,3 +70,30 @@ def test_no_cpu_fallback(capi):
     with pytest.raises(capi.SdrError) as e:
         capi.FirPlan(np.ones(8), 2)
     assert e.value.status in (capi.ENODEV, capi.EHIP)
+
+
+def test_product_build_is_not_a_measurement_build(capi):
+    """kernel ablation switches exist only behind -DSDR_MEASUREMENT_BUILD, which capi.build() never sets"""
+    assert capi.build_info().startswith("libsdrhip product build")
+    src = open(os.path.join(ROOT, "sdr_amd", "capi.py")).read()
+    assert "-DSDR_MEASUREMENT_BUILD" not in src and "-DSDR_I8_ABLATE" not in src and "-DSDR_FFT_ABLATE" not in src
+
+
+def test_apt_image_state_stays_bounded_on_constant_input(capi):
+    """a long run of constant envelope blocks (squelched input) finds no line and must not
+    grow the pending backlog without bound (host code, no device needed)"""
+    img = capi.AptImage(width=2080, rows=8)
+    blk = np.full(8320, 0.25, np.float32)            # 2 s of APT envelope at 4160 Hz
+    pend = []
+    for _ in range(40):
+        assert img.push(blk) == 0
+        pend.append(img.get()[2])
+    assert max(pend) <= 2080 + 500, max(pend)
+    # and a real signal afterwards still synchronises: lines of 2080 samples with a sync pulse train
+    line = np.full(2080, 0.3, np.float32)
+    sync = np.array([0, 0, 0, 0] + [1, 1, 0, 0] * 7 + [0] * 7, np.float32)
+    line[:39] = 0.1 + 0.8 * sync
+    added = 0
+    for _ in range(6):
+        added += img.push(np.tile(line, 4))
+    assert added >= 8, added

@@ -1,0 +1,200 @@
+"""GPU tests at the sizes BASELINE.json names (configs[2] channelizer, configs[3] waterfall) and of
+the multi-rank splits with the HIP kernels doing the per-rank compute (tests/test_shard_gloo.py
+covers the collectives with the CPU oracle standing in for the kernels).
+
+Full-size runs are checked the way ③ asks: against the oracle on slices it finishes in seconds
+(first / middle / last channels and frames) plus size-independent properties -- sentinel-guarded
+output strides, untouched tails, and bit-identity between a sharded and a one-piece run.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TWO_PI = 2.0 * np.pi
+
+
+@pytest.fixture(scope="module")
+def sdr():
+    import sdr_amd
+    sdr_amd.capi.lib()
+    sdr_amd.init(0)
+    return sdr_amd
+
+
+def fill(sdr, buf, value, count, dtype=np.float32, offset_bytes=0, chunk=1 << 24):
+    """fill `count` elements of a DevBuf with a sentinel (chunked uploads)"""
+    blk = np.full(min(chunk, count), value, dtype)
+    done = 0
+    while done < count:
+        k = min(chunk, count - done)
+        sdr.capi.check(sdr.capi.lib().sdr_dev_upload(buf.at(offset_bytes + done * blk.itemsize),
+                                                     blk.ctypes.data_as(C.c_void_p), C.c_size_t(k * blk.itemsize)))
+        done += k
+
+
+def test_cfg3_full_size(sdr, oracle):
+    """BASELINE configs[2]: 1024 channels x 2^20 samples, 64 taps / 10, FM -- one batched launch.
+    Oracle on channels 0 / 511 / 1023; every channel's output row sits between sentinels that must
+    survive (a blockIdx.y or stride slip would land there)."""
+    n_ch, n, D, T = 1024, 1 << 20, 10, 64
+    h = sdr.create_fir_filter(T, 1.0 / D, "hann")
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM)
+    d_in = sdr.DevBuf(n_ch * n * 4)
+    for c in range(n_ch):
+        sdr.capi.synth_fm_i16_dev(d_in.at(c * n * 4), n, fs=1.0e6, ftone=300.0 + 2700.0 * c / (n_ch - 1),
+                                  dev=5000.0, noise_lsb=2, seed=100 + c)
+    cnt = plan.out_count(n)
+    gap = 5
+    stride = cnt + gap
+    SENT = np.float32(-12345.25)
+    d_out = sdr.DevBuf(n_ch * stride * 4)
+    fill(sdr, d_out, SENT, n_ch * stride)
+    plan.execute_batched_dev(d_in, n, n, n_ch, d_out, stride)
+    sdr.sync()
+    out = d_out.to_numpy(np.float32, n_ch * stride).reshape(n_ch, stride)
+    assert (out[:, cnt:] == SENT).all(), "a channel wrote past its row"
+    assert not (out[:, :cnt] == SENT).any(), "outputs missing"
+    assert np.isfinite(out[:, :cnt]).all() and np.abs(out[:, :cnt]).max() <= 0.5
+    for c in (0, 511, 1023):
+        iq = d_in.to_numpy(np.int16, 2 * n, c * n * 4)
+        want = oracle.chain_i16(iq, D, h, oracle.MODE_FM)
+        assert np.abs(out[c, :cnt].astype(np.float64) - want).max() <= 1e-5 * 0.5, c
+    # every channel equals the same channel filtered on its own (same kernel, one channel per launch)
+    d_one = sdr.DevBuf(cnt * 4)
+    for c in (1, 700):
+        plan.execute_dev(d_in.at(c * n * 4), n, d_one, cnt)
+        sdr.sync()
+        assert np.array_equal(d_one.to_numpy(np.float32, cnt), out[c, :cnt]), c
+
+
+def test_cfg4_full_size(sdr, oracle):
+    """BASELINE configs[3]: 2^28 samples, 4096-point Blackman frames at hop 2048 -> 131071 dB rows.
+    Oracle on the first / middle / last frames; the row after the last frame is a sentinel."""
+    n, nfft, hop = 1 << 28, 4096, 2048
+    w = sdr.window("blackman", nfft)
+    plan = sdr.FftPlan(nfft, hop, w)
+    d_in = sdr.DevBuf(n * 4)
+    sdr.capi.synth_fm_i16_dev(d_in, n, fs=61.44e6, ftone=250e3, dev=2.0e6, amp=1200.0, noise_lsb=64, seed=3)
+    frames = plan.frame_count(n)
+    assert frames == 131071
+    SENT = np.float32(777.125)
+    d_out = sdr.DevBuf((frames + 1) * nfft * 4)
+    fill(sdr, d_out, SENT, nfft, offset_bytes=frames * nfft * 4)
+    assert plan.execute_dev(d_in, n, d_out, frames) == frames
+    sdr.sync()
+    assert (d_out.to_numpy(np.float32, nfft, frames * nfft * 4) == SENT).all()
+    worst = 0.0
+    for f0 in (0, 1, frames // 2, 65535, 65536, frames - 4):
+        iq = d_in.to_numpy(np.int16, 2 * (nfft + 3 * hop), f0 * hop * 4)
+        want_db, want_lin = oracle.fft_power_db_i16(iq, nfft, hop, w, linear=True)
+        got = d_out.to_numpy(np.float32, 4 * nfft, f0 * nfft * 4).reshape(4, nfft).astype(np.float64)
+        lin = 10.0 ** (got / 10.0)
+        worst = max(worst, float(np.abs(lin - want_lin).max() / want_lin.max()))
+        strong = want_db >= want_db.max() - 50.0
+        assert np.abs(got - want_db)[strong].max() <= 1e-3, f0
+    assert worst <= 1e-5, worst
+    # property over the whole output: every frame's total power equals the windowed samples' power
+    # (Parseval, 1/N^2 scaling of fftInPlace(x, 1/N)) -- checked on a strided subset of frames
+    win = (w / 2048.0)
+    for f in range(7, frames, 9973):
+        iq = d_in.to_numpy(np.int16, 2 * nfft, f * hop * 4).astype(np.float64)
+        x = (iq[0::2] + 1j * iq[1::2]) * win
+        p_time = float((np.abs(x) ** 2).sum()) / nfft
+        row = d_out.to_numpy(np.float32, nfft, f * nfft * 4).astype(np.float64)
+        p_freq = float((10.0 ** (row / 10.0)).sum())
+        assert abs(p_freq - p_time) <= 1e-4 * p_time, (f, p_freq, p_time)
+
+
+@pytest.mark.parametrize("pipe", [1, 5])
+def test_two_ranks_time_split_through_hip(sdr, oracle, pipe):
+    """shard.plan_time_shards with the HIP kernels as the per-rank compute: two 'ranks' run back to
+    back on this GPU, each holding only its own resident window, and their concatenation must equal
+    the one-piece launch -- bit for bit for the vector-unit kernel, to one float32 ulp for the int8
+    matrix kernel (its outputs are rounded once per tile position)."""
+    from sdr_amd import shard
+    n_total, D, T = 3_000_017, 10, (64 if pipe == 1 else 511)
+    h = sdr.create_fir_filter(T, 0.8 / D, "hann")
+    iq = oracle.synth_fm_i16(n_total, fs=2.0e6, ftone=1500.0, dev=30000.0)
+    rng = np.random.default_rng(1)
+    iq = (iq + rng.integers(-30, 31, iq.size)).astype(np.int16)
+    for mode, smode in ((sdr.MODE_FM, shard.MODE_FM), (sdr.MODE_ENV, shard.MODE_ENV)):
+        plan = sdr.FirPlan(h, D, mode=mode, pipeline=pipe)
+        cnt = plan.out_count(n_total)
+        d_all = sdr.DevBuf.from_numpy(iq)
+        d_one = sdr.DevBuf(cnt * 4)
+        assert plan.execute_dev(d_all, n_total, d_one, cnt) == cnt
+        sdr.sync()
+        one = d_one.to_numpy(np.float32, cnt)
+        parts = []
+        for sh in shard.plan_time_shards(n_total, D, T, smode, 2):
+            d_res = sdr.DevBuf.from_numpy(iq[2 * sh.lo: 2 * sh.hi])          # this rank's window only
+            d_out = sdr.DevBuf(max(sh.n_out, 1) * 4)
+            plan.execute_range_dev(d_res, sh.lo, sh.n_resident, n_total, sh.out_begin, sh.out_end, d_out)
+            sdr.sync()
+            parts.append(d_out.to_numpy(np.float32, sh.n_out))
+        got = np.concatenate(parts)
+        assert got.shape == one.shape
+        if pipe == 1:
+            assert np.array_equal(got, one)
+        else:
+            assert np.abs(got.astype(np.float64) - one).max() <= 2e-6
+        # and the one-piece result is the oracle's
+        want = oracle.chain_i16(iq, D, h, oracle.MODE_FM if mode == sdr.MODE_FM else oracle.MODE_ENV)
+        assert np.abs(one.astype(np.float64)[T:] - want[T:]).max() <= 1e-5 * (0.5 if mode == sdr.MODE_FM else 1.0)
+
+
+def test_two_ranks_channel_and_frame_split_through_hip(sdr, oracle):
+    """shard.plan_channel_shards / plan_frame_shards with the HIP kernels as the per-rank compute"""
+    from sdr_amd import shard
+    # channels: 37 channels over 2 ranks (19 + 18)
+    n_ch, n, D, T = 37, 65_536, 10, 64
+    h = sdr.create_fir_filter(T, 1.0 / D, "hann")
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM)
+    d_in = sdr.DevBuf(n_ch * n * 4)
+    for c in range(n_ch):
+        sdr.capi.synth_fm_i16_dev(d_in.at(c * n * 4), n, fs=1.0e6, ftone=300.0 + 70.0 * c, dev=5000.0, noise_lsb=2, seed=c)
+    cnt = plan.out_count(n)
+    d_one = sdr.DevBuf(n_ch * cnt * 4)
+    plan.execute_batched_dev(d_in, n, n, n_ch, d_one, cnt)
+    sdr.sync()
+    one = d_one.to_numpy(np.float32, n_ch * cnt)
+    parts = []
+    for c0, k in shard.plan_channel_shards(n_ch, 2):
+        host = d_in.to_numpy(np.int16, 2 * k * n, c0 * n * 4)                  # what this rank would hold
+        d_r = sdr.DevBuf.from_numpy(host)
+        d_o = sdr.DevBuf(k * cnt * 4)
+        plan.execute_batched_dev(d_r, n, n, k, d_o, cnt)
+        sdr.sync()
+        parts.append(d_o.to_numpy(np.float32, k * cnt))
+    assert np.array_equal(np.concatenate(parts), one)
+    want = oracle.chain_i16(d_in.to_numpy(np.int16, 2 * n, 36 * n * 4), D, h, oracle.MODE_FM)
+    assert np.abs(one[36 * cnt:].astype(np.float64) - want).max() <= 1e-5 * 0.5
+    # frames: 4096-point frames at hop 2048 over 2 ranks
+    nfft, hop, ns = 4096, 2048, 1 << 22
+    w = sdr.window("blackman", nfft)
+    fplan = sdr.FftPlan(nfft, hop, w)
+    d_s = sdr.DevBuf(ns * 4)
+    sdr.capi.synth_fm_i16_dev(d_s, ns, fs=61.44e6, ftone=250e3, dev=2.0e6, amp=1200.0, noise_lsb=64, seed=3)
+    frames = fplan.frame_count(ns)
+    d_f = sdr.DevBuf(frames * nfft * 4)
+    assert fplan.execute_dev(d_s, ns, d_f, frames) == frames
+    sdr.sync()
+    one = d_f.to_numpy(np.float32, frames * nfft)
+    parts = []
+    for f0, f1, lo, hi in shard.plan_frame_shards(ns, nfft, hop, 2):
+        host = d_s.to_numpy(np.int16, 2 * (hi - lo), lo * 4)
+        d_r = sdr.DevBuf.from_numpy(host)
+        d_o = sdr.DevBuf((f1 - f0) * nfft * 4)
+        assert fplan.execute_dev(d_r, hi - lo, d_o, f1 - f0) == f1 - f0
+        sdr.sync()
+        parts.append(d_o.to_numpy(np.float32, (f1 - f0) * nfft))
+    got = np.concatenate(parts)
+    # different kernels may serve the two sizes (persistent pair kernel vs one frame per slot): same
+    # arithmetic per frame, so the rows agree to float32 rounding of the dB value
+    assert got.shape == one.shape
+    fin = np.isfinite(one)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert np.abs(got[fin] - one[fin]).max() <= 1e-3

@@ -11,7 +11,7 @@ O="sdr_amd/build/lib.o sdr_amd/build/fir.o sdr_amd/build/stream.o sdr_amd/build/
 case "${1:-build}" in
 build)
   for v in $VARS; do
-    hipcc $F -DSDR_FFT_ABLATE=$v -c sdr_amd/csrc/fft.hip -o tools/exp/fft_abl$v.o &
+    hipcc $F -DSDR_MEASUREMENT_BUILD -DSDR_FFT_ABLATE=$v -c sdr_amd/csrc/fft.hip -o tools/exp/fft_abl$v.o &
   done
   wait
   for v in $VARS; do

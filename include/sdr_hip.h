@@ -247,6 +247,23 @@ int sdr_fft_execute_i16_dev(sdr_fft_plan *plan, const int16_t *d_iq, size_t n_in
                             float *d_out_db, size_t frame_capacity, size_t *n_frames,
                             void *stream);
 
+/* Allocation-free variant of sdr_fft_execute_i16_dev.  It has NO counterpart in the reference: it
+ * exists for callers that cannot allocate device memory at the call -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same results bit for bit,
+ * and no hipMalloc / hipFree / allocating library routine on any path: frames longer than 4096
+ * points, whose multi-pass transform needs two scratch arrays (sdr_fft_execute_i16_dev allocates and
+ * grows them inside the plan on demand), take them from a file-scope device array of the library
+ * instead -- 2 MiB per GPU, held until the process ends, resolved once per device by sdr_init() or
+ * by the first call on that device.
+ *   Limit: nfft <= 131072 (the reference's own capture block, bladerf_main_v1.cpp:139); larger
+ *   plans return SDR_EINVAL with a text that says so.
+ *   Every call on one GPU shares that GPU's array (its contents are overwritten before they are
+ *   read, so nothing needs clearing): calls that overlap in time on one GPU -- different streams,
+ *   different plans -- race.  Serialise them, or use sdr_fft_execute_i16_dev. */
+int sdr_fft_execute_i16_noalloc_dev(sdr_fft_plan *plan, const int16_t *d_iq, size_t n_in,
+                                    float *d_out_db, size_t frame_capacity, size_t *n_frames,
+                                    void *stream);
+
 /* ---- a6 (waterfall row): |x|/2048 straight from int16 --------------------------------------
  * Replaces the std::transform at bladerf_waterfall_main.cpp:272. */
 int sdr_magnitude_i16_dev(const int16_t *d_iq, size_t n, float *d_mag, void *stream);

@@ -295,6 +295,14 @@ class FftPlan:
                                             C.c_void_p(stream or 0)))
         return nf.value
 
+    def execute_noalloc_dev(self, d_iq, n_in, d_out, frame_capacity, stream=None):
+        """sdr_fft_execute_i16_noalloc_dev: no device allocation on any path (nfft <= 131072)"""
+        nf = C.c_size_t()
+        check(lib().sdr_fft_execute_i16_noalloc_dev(self.h, _vp(d_iq), C.c_size_t(n_in), _vp(d_out),
+                                                    C.c_size_t(frame_capacity), C.byref(nf),
+                                                    C.c_void_p(stream or 0)))
+        return nf.value
+
     def time_dev(self, d_iq, n_in, d_out, iters, stream=None):
         ms = C.c_float()
         check(lib().sdr_fft_time_dev(self.h, _vp(d_iq), C.c_size_t(n_in), _vp(d_out),

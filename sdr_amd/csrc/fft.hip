@@ -16,6 +16,7 @@
 // Twiddles come from a table exp(-2*pi*i*k/N) in global memory (L1/L2 resident).
 
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "sdr_internal.h"
@@ -557,6 +558,45 @@ int measurement_flags_fft() { return 0; }
 #endif
 }  // namespace sdr
 
+// ---------------------------------------------------------------------------------------------
+// Scratch of the allocation-free entry point sdr_fft_execute_i16_noalloc_dev: the two ping-pong
+// arrays of the multi-pass transform for frames of up to kStaticFftPoints points, in a file-scope
+// device array instead of hipMalloc'ed plan scratch (2 x 131072 x 8 B = 2 MiB, held by every GPU the
+// library runs on until the process ends).  In host code the array's NAME is only a stand-in, not a
+// device address: the address comes from hipGetSymbolAddress, once per device with that device
+// current (each GPU has its own copy at its own address), and everything host-side -- kernel
+// arguments included -- uses that pointer.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kStaticFftPoints = 131072;      // the reference's capture block, bladerf_main_v1.cpp:139
+constexpr int kMaxDevices = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char g_fft_static_scratch[2 * kStaticFftPoints * sizeof(cf)];
+namespace {
+cf *g_fft_scratch_ptr[kMaxDevices] = {};
+std::mutex g_fft_scratch_mtx;
+}  // namespace
+
+namespace sdr {
+// Resolve the scratch array's address on the CURRENT device (idempotent).  Called by sdr_init() for the
+// device it selects and by the entry point on its first call on a device.
+int fft_static_scratch_init(void **ptr_out)
+{
+    int dev = -1;
+    SDR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) { set_error("device ordinal %d beyond %d", dev, kMaxDevices - 1); return SDR_EINVAL; }
+    std::lock_guard<std::mutex> lock(g_fft_scratch_mtx);
+    if (!g_fft_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        SDR_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_fft_static_scratch)));
+        if (!ptr) { set_error("hipGetSymbolAddress returned a null scratch address"); return SDR_EHIP; }
+        g_fft_scratch_ptr[dev] = (cf *)ptr;
+    }
+    if (ptr_out) *ptr_out = g_fft_scratch_ptr[dev];
+    return SDR_OK;
+}
+}  // namespace sdr
+
 struct sdr_fft_plan {
     int nfft, hop;
     int n_cu = 256;
@@ -580,6 +620,39 @@ long long frame_count(const sdr_fft_plan *p, long long n)
     return (n - p->nfft) / p->hop + 1;
 }
 
+// the multi-pass transform of `frames` frames, `per` frames per round, through two scratch arrays of
+// per * nfft complex values each
+int run_fft_big(const sdr_fft_plan *p, const int16_t *d_iq, float *d_out, long long frames, long long per,
+                cf *scr0, cf *scr1, hipStream_t st)
+{
+    const int n = p->nfft;
+    cf *scr[2] = {scr0, scr1};
+    const uint32_t *in = (const uint32_t *)d_iq;
+    int log2n = 0;
+    while ((1 << log2n) < n) ++log2n;
+    const int n4 = log2n / 2, n2 = log2n & 1;                // radix-4 passes, then one radix-2 pass
+    for (long long f0 = 0; f0 < frames; f0 += per) {
+        const unsigned nf = (unsigned)(frames - f0 < per ? frames - f0 : per);
+        int ns = 1, cur = 0;
+        for (int ps = 0; ps < n4 + n2; ++ps) {
+            const bool first = ps == 0, last = ps == n4 + n2 - 1;
+            const int R = ps < n4 ? 4 : 2;
+            const dim3 grid((unsigned)((n / R + 255) / 256), nf);
+            const cf *src = scr[cur];
+            cf *dst = scr[cur ^ 1];
+#define SDR_BIG(RR, FI, LA) fft_big_pass_kernel<RR, FI, LA><<<grid, 256, 0, st>>>(in, p->d_win, src, dst, d_out, n, ns, (long long)p->hop, f0)
+            if (R == 4) { if (first) SDR_BIG(4, true, false); else if (last) SDR_BIG(4, false, true); else SDR_BIG(4, false, false); }
+            else { if (last) SDR_BIG(2, false, true); else SDR_BIG(2, false, false); }
+#undef SDR_BIG
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return sdr::hip_fail(e, "fft pass launch");
+            ns *= R;
+            cur ^= 1;
+        }
+    }
+    return SDR_OK;
+}
+
 int launch_fft_big(sdr_fft_plan *p, const int16_t *d_iq, float *d_out, long long frames, hipStream_t st)
 {
     const int n = p->nfft;
@@ -596,38 +669,22 @@ int launch_fft_big(sdr_fft_plan *p, const int16_t *d_iq, float *d_out, long long
         SDR_HIP(hipMalloc((void **)&p->d_scr[1], need * sizeof(cf)));
         p->cap_scr = need;
     }
-    const uint32_t *in = (const uint32_t *)d_iq;
-    int log2n = 0;
-    while ((1 << log2n) < n) ++log2n;
-    const int n4 = log2n / 2, n2 = log2n & 1;                // radix-4 passes, then one radix-2 pass
-    for (long long f0 = 0; f0 < frames; f0 += per) {
-        const unsigned nf = (unsigned)(frames - f0 < per ? frames - f0 : per);
-        int ns = 1, cur = 0;
-        for (int ps = 0; ps < n4 + n2; ++ps) {
-            const bool first = ps == 0, last = ps == n4 + n2 - 1;
-            const int R = ps < n4 ? 4 : 2;
-            const dim3 grid((unsigned)((n / R + 255) / 256), nf);
-            const cf *src = p->d_scr[cur];
-            cf *dst = p->d_scr[cur ^ 1];
-#define SDR_BIG(RR, FI, LA) fft_big_pass_kernel<RR, FI, LA><<<grid, 256, 0, st>>>(in, p->d_win, src, dst, d_out, n, ns, (long long)p->hop, f0)
-            if (R == 4) { if (first) SDR_BIG(4, true, false); else if (last) SDR_BIG(4, false, true); else SDR_BIG(4, false, false); }
-            else { if (last) SDR_BIG(2, false, true); else SDR_BIG(2, false, false); }
-#undef SDR_BIG
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return sdr::hip_fail(e, "fft pass launch");
-            ns *= R;
-            cur ^= 1;
-        }
-    }
-    return SDR_OK;
+    return run_fft_big(p, d_iq, d_out, frames, per, p->d_scr[0], p->d_scr[1], st);
 }
 
+// static_scr != nullptr: the allocation-free entry point -- long frames take their two scratch arrays
+// from it (2 x kStaticFftPoints complex values) instead of the plan's heap scratch
 int launch_fft(sdr_fft_plan *p, const int16_t *d_iq, long long n_in, float *d_out,
-               long long frames, hipStream_t st)
+               long long frames, hipStream_t st, cf *static_scr = nullptr)
 {
     if (frames == 0) return SDR_OK;
     if (((uintptr_t)d_iq) & 3 || ((uintptr_t)d_out) & 3) { sdr::set_error("misaligned pointer"); return SDR_EALIGN; }
     if (int rc = sdr::same_device(p->device)) return rc;
+    if (p->nfft > 4096 && static_scr) {
+        long long per = (long long)kStaticFftPoints / p->nfft;          // >= 1: the entry point checked nfft
+        if (per > frames) per = frames;
+        return run_fft_big(p, d_iq, d_out, frames, per, static_scr, static_scr + kStaticFftPoints, st);
+    }
     if (p->nfft > 4096) return launch_fft_big(p, d_iq, d_out, frames, st);
     FftGeom g;
     g.n_in = n_in; g.frames = frames; g.hop = p->hop; g.dummy = p->d_dummy;
@@ -745,6 +802,30 @@ extern "C" int sdr_fft_execute_i16_dev(sdr_fft_plan *p, const int16_t *d_iq, siz
     if (frames == 0) return SDR_OK;
     if (!d_iq || !d_out) { sdr::set_error("null argument"); return SDR_EINVAL; }
     return launch_fft(p, d_iq, (long long)n_in, d_out, frames, (hipStream_t)stream);
+}
+
+// The allocation-free variant (no counterpart in the reference; see sdr_hip.h): same result as
+// sdr_fft_execute_i16_dev, no hipMalloc / hipFree on any path.  Frames longer than 4096 points run the
+// same multi-pass kernels through the static scratch array, kStaticFftPoints / nfft frames per round.
+extern "C" int sdr_fft_execute_i16_noalloc_dev(sdr_fft_plan *p, const int16_t *d_iq, size_t n_in,
+                                               float *d_out, size_t frame_capacity, size_t *n_frames,
+                                               void *stream)
+{
+    if (!p) { sdr::set_error("null plan"); return SDR_EINVAL; }
+    if ((size_t)p->nfft > kStaticFftPoints) {
+        sdr::set_error("sdr_fft_execute_i16_noalloc_dev: nfft %d exceeds the static scratch limit of %zu points "
+                       "(use sdr_fft_execute_i16_dev, which allocates plan scratch)", p->nfft, kStaticFftPoints);
+        return SDR_EINVAL;
+    }
+    const long long frames = frame_count(p, (long long)n_in);
+    if (n_frames) *n_frames = (size_t)frames;
+    if ((size_t)frames > frame_capacity) { sdr::set_error("frame capacity %zu < %lld", frame_capacity, frames); return SDR_ECAPACITY; }
+    if (frames == 0) return SDR_OK;
+    if (!d_iq || !d_out) { sdr::set_error("null argument"); return SDR_EINVAL; }
+    if (int rc = sdr::same_device(p->device)) return rc;
+    void *scr = nullptr;
+    if (int rc = sdr::fft_static_scratch_init(&scr)) return rc;       // a table look-up after the first call
+    return launch_fft(p, d_iq, (long long)n_in, d_out, frames, (hipStream_t)stream, (cf *)scr);
 }
 
 extern "C" int sdr_fft_execute_i16_host(sdr_fft_plan *p, const int16_t *iq, size_t n_in,

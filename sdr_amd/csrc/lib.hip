@@ -44,6 +44,8 @@ static int check_device(int dev)
     }
     SDR_HIP(hipSetDevice(dev));
     g_ready_device = dev;
+    // with the device current: resolve the static scratch of the allocation-free FFT entry point
+    if (int rc = fft_static_scratch_init(nullptr)) return rc;
     return SDR_OK;
 }
 

@@ -33,6 +33,7 @@ int same_device(int plan_device);   // SDR_OK when the calling thread's current 
 #error "kernel ablation switches need -DSDR_MEASUREMENT_BUILD: such a library computes wrong results on purpose"
 #endif
 #endif
+int fft_static_scratch_init(void **ptr_out);   // fft.hip: address of the no-alloc scratch on the current device
 int measurement_flags_fir();  // 0 in the product; the ablation mask of fir.hip in a measurement build (-1: none set)
 int measurement_flags_fft();  // the same for fft.hip
 

@@ -53,11 +53,11 @@ private:
 class FirPlan {
 public:
     FirPlan(const std::vector<double>& taps, int decim, int mode, int input, double scale = 1.0,
-            double mix_fr = 0.0)
+            double mix_fr = 0.0, int count_rule = SDR_COUNT_FLOOR)
     {
         sdr_fir_desc d{};
         d.input = input; d.mode = mode; d.decim = decim; d.n_taps = (int)taps.size();
-        d.taps = taps.data(); d.scale = scale; d.mix_fr = mix_fr;
+        d.taps = taps.data(); d.scale = scale; d.mix_fr = mix_fr; d.count_rule = count_rule;
         check(sdr_fir_plan_create(&d, &p_));
     }
     ~FirPlan() { sdr_fir_plan_destroy(p_); }
@@ -102,17 +102,45 @@ inline std::vector<float> shift_decimate_envelope(const std::vector<float>& x, d
     return plan.run<float, float>(x.data(), x.size());
 }
 
+// bladerf_fm_demod.cpp:288-298 in one launch, on the float block the reference's source hands over:
+//   x3 = af::fir(af_lpf, x2);  x4 = x3(dec_seq);  x5 = atan2(imag, real)(x4(1:end) * conjg(x4(0:end-1))) * phasor_scale
+// dec_seq = af::seq(0, num_samples, dec_rate) has an inclusive end, hence SDR_COUNT_AF_SEQ (sdr_hip.h).
+inline std::vector<float> af_fir_pick_discriminate(const std::vector<std::complex<float>>& x2,
+                                                   const std::vector<float>& lpf, int dec_rate, double phasor_scale)
+{
+    FirPlan plan(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_FM, SDR_IN_CF32, phasor_scale, 0.0,
+                 SDR_COUNT_AF_SEQ);
+    return plan.run<std::complex<float>, float>(x2.data(), x2.size());
+}
+// the same from the raw int16 block (the scale loop of bladerf_sdr.h:288-291 fused in as well)
+inline std::vector<float> af_fir_pick_discriminate_i16(const std::vector<std::complex<int16_t>>& iq,
+                                                       const std::vector<float>& lpf, int dec_rate, double phasor_scale)
+{
+    FirPlan plan(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_FM, SDR_IN_I16_IQ, phasor_scale, 0.0,
+                 SDR_COUNT_AF_SEQ);
+    return plan.run<std::complex<int16_t>, float>(iq.data(), iq.size());
+}
+// bladerf_am_demod.cpp:294-311: af::fir, x3(dec_seq), af::abs
+inline std::vector<float> af_fir_pick_abs(const std::vector<std::complex<float>>& x2, const std::vector<float>& lpf,
+                                          int dec_rate)
+{
+    FirPlan plan(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_ENV, SDR_IN_CF32, 1.0, 0.0, SDR_COUNT_AF_SEQ);
+    return plan.run<std::complex<float>, float>(x2.data(), x2.size());
+}
+
 // bladerf_fm_demod.cpp:301-313: de-emphasis FIR, audio low-pass FIR, pick every dec_audio-th sample,
 // normalise to +-1 and convert to unsigned 8-bit PCM.  The two full-rate filters are folded into
 // one (their convolution), so only the kept samples are computed -- one real-input FIR/decimate
-// launch plus the PCM stage.
+// launch plus the PCM stage.  count_rule: SDR_COUNT_AF_SEQ picks like x6(seq_audio) (:227,307; the
+// seq's indices past the end of x6 are not read), SDR_COUNT_FLOOR keeps floor(n / dec_audio) samples.
 inline std::vector<uint8_t> fm_audio_u8(const std::vector<float>& x5, const std::vector<float>& lpf_de,
-                                        const std::vector<float>& lpf_a, int dec_audio)
+                                        const std::vector<float>& lpf_a, int dec_audio,
+                                        int count_rule = SDR_COUNT_FLOOR)
 {
     std::vector<double> hc(lpf_de.size() + lpf_a.size() - 1, 0.0);
     for (size_t i = 0; i < lpf_de.size(); ++i)
         for (size_t j = 0; j < lpf_a.size(); ++j) hc[i + j] += (double)lpf_de[i] * (double)lpf_a[j];
-    FirPlan plan(hc, dec_audio, SDR_MODE_REAL, SDR_IN_F32_REAL);
+    FirPlan plan(hc, dec_audio, SDR_MODE_REAL, SDR_IN_F32_REAL, 1.0, 0.0, count_rule);
     const size_t m = plan.out_count(x5.size());
     std::vector<uint8_t> pcm(m);
     if (m == 0) return pcm;

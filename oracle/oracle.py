@@ -387,17 +387,19 @@ def ref_time_chain_i16(iq, D, h, mode, scale, reps):
                                     C.c_int(reps), C.byref(sink))
 
 
-def fm_audio_chain(x5, h_de, h_a, D):
-    """bladerf_fm_demod.cpp:301-313 -> (normalised audio float64, pcm uint8)"""
+def fm_audio_chain(x5, h_de, h_a, D, af_seq=False):
+    """bladerf_fm_demod.cpp:301-313 -> (normalised audio float64, pcm uint8); af_seq: keep the samples
+    x6(seq_audio) picks (every index 0, D, ... <= n-1) instead of floor(n/D)"""
     x = _f64(x5)
     h_de = _f64(h_de)
     h_a = _f64(h_a)
-    m = x.size // D
+    m = x.size // D + 1
     audio = np.zeros(max(m, 1), np.float64)
     pcm = np.zeros(max(m, 1), np.uint8)
-    k = lib().orc_fm_audio_chain(_d(x), C.c_size_t(x.size), _d(h_de), C.c_int(h_de.size), _d(h_a),
-                                 C.c_int(h_a.size), C.c_int(D), _d(audio),
-                                 pcm.ctypes.data_as(C.c_void_p))
+    lib().orc_fm_audio_chain_rule.restype = C.c_size_t
+    k = lib().orc_fm_audio_chain_rule(_d(x), C.c_size_t(x.size), _d(h_de), C.c_int(h_de.size), _d(h_a),
+                                      C.c_int(h_a.size), C.c_int(D), C.c_int(1 if af_seq else 0), _d(audio),
+                                      pcm.ctypes.data_as(C.c_void_p))
     return audio[:k], pcm[:k]
 
 

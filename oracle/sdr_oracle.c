@@ -492,8 +492,20 @@ void orc_synth_fm_i16(int16_t *iq, size_t n, uint64_t n0, double fs, double fton
  * index one past the data); an all-zero block gives 30 (the reference divides by zero).
  * x5: n floats as doubles; audio (optional): floor(n/D) normalised values before quantisation;
  * pcm: floor(n/D) bytes.  Returns floor(n/D). */
+size_t orc_fm_audio_chain_rule(const double *x5, size_t n, const double *h_de, int T_de,
+                               const double *h_a, int T_a, int D, int af_seq, double *audio, uint8_t *pcm);
 size_t orc_fm_audio_chain(const double *x5, size_t n, const double *h_de, int T_de,
                           const double *h_a, int T_a, int D, double *audio, uint8_t *pcm)
+{
+    return orc_fm_audio_chain_rule(x5, n, h_de, T_de, h_a, T_a, D, 0, audio, pcm);
+}
+
+/* af_seq != 0: the kept indices are those of x6(seq_audio), seq_audio = af::seq(0, dec_seq.dims(0),
+ * dec_audio) (bladerf_fm_demod.cpp:227,307), that lie inside x6: 0, D, 2D, ... <= n-1, i.e.
+ * floor((n-1)/D)+1 samples (dec_seq.dims(0) is n+1 or n+2, so the seq reaches at least n-1; its
+ * indices >= n would be out of bounds in the reference and are not picked). */
+size_t orc_fm_audio_chain_rule(const double *x5, size_t n, const double *h_de, int T_de,
+                               const double *h_a, int T_a, int D, int af_seq, double *audio, uint8_t *pcm)
 {
     if (D <= 0 || T_de <= 0 || T_a <= 0) return 0;
     double *a = (double *)calloc(n ? n : 1, sizeof(double));
@@ -508,7 +520,7 @@ size_t orc_fm_audio_chain(const double *x5, size_t n, const double *h_de, int T_
         for (int k = 0; k < T_a && (size_t)k <= i; ++k) acc += h_a[k] * a[i - k];
         b[i] = acc;
     }
-    const size_t m = n / (size_t)D;
+    const size_t m = af_seq ? (n ? (n - 1) / (size_t)D + 1 : 0) : n / (size_t)D;
     double mx = 0.0;
     for (size_t j = 0; j < m; ++j) { const double v = fabs(b[j * D]); if (v > mx) mx = v; }
     const double r = mx > 0.0 ? 1.0 / mx : 0.0;

@@ -61,6 +61,63 @@ def test_reference_loop_through_shims(golden, oracle, tmp_path):
     assert d.max() <= 1 and np.count_nonzero(d) <= max(4, pcm.size // 500)
 
 
+def test_fm_loop_through_source_shim(oracle, tmp_path):
+    """bladerf_fm_demod.cpp:279-313 compiled against include/sdr_hip_source.hpp + sdr_hip_shims.hpp
+    (examples/fm_chain_example.cpp): SDR_BASE::build() -> start / wait_for_samples / stop over a
+    recording, af::fir + x3(dec_seq) + discriminator, audio chain.  Every block restarts from zero
+    state like the reference's loop; ArrayFire is absent, so the oracle restates its documented
+    semantics (fir_pick: inclusive af::seq end) -- parity unpinned beyond that."""
+    exe = os.path.join(ROOT, "examples", "bin", "fm_chain_example")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    blk, nblk = 4096 * 32, 3
+    n = blk * nblk + 1000                              # the tail shorter than a block is never delivered
+    # one block for start_single, then nblk-1 full blocks through start()/wait_for_samples()
+    iq = oracle.synth_fm_i16(n, fs=1.0e6, ftone=1000.0, dev=60000.0, amp=1800.0)
+    rng = np.random.default_rng(4)
+    iq = (iq + rng.integers(-20, 21, iq.size)).astype(np.int16)
+    src = tmp_path / "fm.sc16"
+    iq.tofile(src)
+    pfx = str(tmp_path / "fm")
+    r = subprocess.run([exe, str(src), pfx], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"blocks {nblk - 1} " in r.stdout, r.stdout
+    lpf = np.fromfile(pfx + ".lpf.f32", np.float32)
+    h_de = np.fromfile(pfx + ".lpf_de.f32", np.float32)
+    h_a = np.fromfile(pfx + ".lpf_a.f32", np.float32)
+    assert lpf.size == 101 and h_de.size == 64 and h_a.size == 101
+    D, Da = 5, 4                                       # fs / channel_bw, fs_d / audio_freq (test_case 1)
+    scale = float(np.float32(1.0 / (2.0 * np.pi)))     # float phasor_scale = 1 / ((2*M_PI) / (fs_d / channel_bw)), :224
+    # start_single: the a2 conversion, bit exact
+    single = np.fromfile(pfx + ".single.f32", np.float32)
+    want = oracle.unpack_scale_i16(iq[: 2 * blk]).astype(np.complex64).view(np.float32)
+    assert single.tobytes() == want.tobytes()
+    x5 = np.fromfile(pfx + ".x5.f32", np.float32).astype(np.float64)
+    x5raw = np.fromfile(pfx + ".x5raw.f32", np.float32).astype(np.float64)
+    pcm = np.fromfile(pfx + ".pcm.u8", np.uint8)
+    n4 = (blk - 1) // D + 1                            # x3(dec_seq) keeps 26215 of 131072 / 5 (floor rule: 26214)
+    assert n4 == 26215 and x5.size == (nblk - 1) * (n4 - 1) == x5raw.size
+    na = (n4 - 2) // Da + 1
+    assert pcm.size == (nblk - 1) * na
+    fs_full = abs(scale) * np.pi
+    for b in range(nblk - 1):
+        cf = oracle.unpack_scale_i16(iq[2 * blk * (b + 1): 2 * blk * (b + 2)]).astype(np.complex64).astype(np.complex128)
+        y = oracle.fir_pick(cf, D, lpf)
+        want5 = oracle.polar_discriminator(y, scale)
+        settle = 101 // D + 2                          # start-up transient: ill-conditioned angles (sdr_hip.h, rule 2)
+        for got in (x5, x5raw):
+            g = got[b * (n4 - 1): (b + 1) * (n4 - 1)]
+            d = np.abs(g - want5)
+            d = np.minimum(d, np.abs(2 * fs_full - d))
+            assert d[settle:].max() <= 1e-5 * fs_full, (b, float(d[settle:].max()))
+        # audio chain on the kernel's own x5 (float32), AF seq count
+        g5 = np.fromfile(pfx + ".x5.f32", np.float32)[b * (n4 - 1): (b + 1) * (n4 - 1)]
+        _, want_pcm = oracle.fm_audio_chain(g5, h_de, h_a, Da, af_seq=True)
+        got_pcm = pcm[b * na: (b + 1) * na]
+        assert got_pcm.shape == want_pcm.shape
+        dd = np.abs(got_pcm.astype(np.int32) - want_pcm.astype(np.int32))
+        assert dd.max() <= 1 and np.count_nonzero(dd) <= max(4, got_pcm.size // 500)
+
+
 @pytest.mark.parametrize("mode", ["fm", "env", "iq"])
 def test_stream_blocks_equal_one_shot(sdr, oracle, mode):
     """a12: pushing blocks through sdr_fir_stream gives the one-shot result on the concatenation

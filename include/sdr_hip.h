@@ -240,6 +240,13 @@ int sdr_fir_execute_batched_dev(sdr_fir_plan *plan, const void *d_in, size_t n_i
  * kernels with plan-owned scratch).  window may be NULL (rectangular). */
 int sdr_fft_plan_create(int nfft, int hop, const double *window, sdr_fft_plan **plan);
 int sdr_fft_plan_destroy(sdr_fft_plan *plan);
+/* Kernel choice for 4096-point frames at hop 2048 on long streams (tuning / A-B measurement knob; every
+ * variant computes the same transform): 0 = automatic, 1 = one frame per 256-lane workgroup with
+ * barrier-separated LDS exchanges (fft_db_kernel), 2 = two frames per lane (fft4096_pair_kernel),
+ * 3 = one frame per wavefront, barrier-free, four waves per CU (fft4096_wave_kernel<false>),
+ * 4 = the same with eight waves per CU (fft4096_wave_kernel<true>; the automatic choice).  Other
+ * shapes ignore it. */
+int sdr_fft_plan_set_variant(sdr_fft_plan *plan, int variant);
 size_t sdr_fft_frame_count(const sdr_fft_plan *plan, size_t n_in);
 int sdr_fft_execute_i16_host(sdr_fft_plan *plan, const int16_t *iq, size_t n_in, float *out_db,
                              size_t frame_capacity, size_t *n_frames);

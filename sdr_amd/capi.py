@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDRHIP_LIB") or os.path.join(_HERE, "libsdrhip.so")   # override: kernel experiments
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "stream.hip", "apt.hip", "lib.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "fft_wave.hip", "stream.hip", "apt.hip", "lib.hip")]
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 OK, EINVAL, ENOMEM, EHIP, EALIGN, ECAPACITY, ENODEV, ERANGE = range(8)
@@ -39,13 +39,16 @@ class FirDesc(C.Structure):
 # per-file compiler flags: the FFT's complex butterflies lose ~12 % when the SLP vectoriser pairs
 # them into v_pk_add_f32 (same issue cost as two scalar adds on gfx950, plus the moves that build
 # the register pairs); the FIR walk gains from v_pk_fma_f32 and keeps the default
-EXTRA_FLAGS = {"fft.hip": ["-fno-slp-vectorize"]}
+# fft_wave.hip (one 4096-point frame per wavefront) is bound by vector-instruction issue: the max-ILP
+# scheduling strategy leaves fewer dependent-issue stalls there (0.723 vs 0.734 ms per 2^28 samples)
+EXTRA_FLAGS = {"fft.hip": ["-fno-slp-vectorize"],
+               "fft_wave.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def build(force=False):
     """hipcc -> sdr_amd/libsdrhip.so (cross-compiles for gfx950 without a GPU)."""
     srcs = [s for s in SOURCES if os.path.exists(s)]
-    deps = srcs + [os.path.join(_HERE, "csrc", "sdr_internal.h"),
+    deps = srcs + [os.path.join(_HERE, "csrc", "sdr_internal.h"), os.path.join(_HERE, "csrc", "fft_common.h"),
                    os.path.join(INCLUDE, "sdr_hip.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
@@ -276,6 +279,10 @@ class FftPlan:
 
     def frame_count(self, n_in):
         return lib().sdr_fft_frame_count(self.h, n_in)
+
+    def set_variant(self, variant):
+        """0 auto, 1 workgroup exchange, 2 two frames per lane, 3 one frame per wavefront"""
+        check(lib().sdr_fft_plan_set_variant(self.h, C.c_int(variant)))
 
     def execute_host(self, iq):
         a = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1)

@@ -76,16 +76,16 @@ int same_device(int plan_device)
 extern "C" const char *sdr_build_info(void)
 {
     static char text[256];
-    const int fir = sdr::measurement_flags_fir(), fft = sdr::measurement_flags_fft();
-    if (!fir && !fft) return "libsdrhip product build (gfx950)";
+    const int fir = sdr::measurement_flags_fir(), fft = sdr::measurement_flags_fft(), fftw = sdr::measurement_flags_fft_wave();
+    if (!fir && !fft && !fftw) return "libsdrhip product build (gfx950)";
     snprintf(text, sizeof(text), "libsdrhip MEASUREMENT BUILD -- results are wrong by construction "
-             "(fir.hip ablation mask %d, fft.hip ablation mask %d; -1 = built with SDR_MEASUREMENT_BUILD, no mask)", fir, fft);
+             "(ablation masks: fir.hip %d, fft.hip %d, fft_wave.hip %d; -1 = built with SDR_MEASUREMENT_BUILD, no mask)", fir, fft, fftw);
     return text;
 }
 
 extern "C" int sdr_init(int device)
 {
-    if (sdr::measurement_flags_fir() || sdr::measurement_flags_fft()) fprintf(stderr, "%s\n", sdr_build_info());
+    if (sdr::measurement_flags_fir() || sdr::measurement_flags_fft() || sdr::measurement_flags_fft_wave()) fprintf(stderr, "%s\n", sdr_build_info());
     return sdr::check_device(device);
 }
 

@@ -36,6 +36,7 @@ int same_device(int plan_device);   // SDR_OK when the calling thread's current 
 int fft_static_scratch_init(void **ptr_out);   // fft.hip: address of the no-alloc scratch on the current device
 int measurement_flags_fir();  // 0 in the product; the ablation mask of fir.hip in a measurement build (-1: none set)
 int measurement_flags_fft();  // the same for fft.hip
+int measurement_flags_fft_wave();  // and for fft_wave.hip
 
 // 2^-11: the Q11 scale of BLADERF_FORMAT_SC16_Q11 samples (bladerf_sdr.h:274)
 constexpr float kQ11 = 1.0f / 2048.0f;

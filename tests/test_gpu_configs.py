@@ -192,9 +192,12 @@ def test_two_ranks_channel_and_frame_split_through_hip(sdr, oracle):
         sdr.sync()
         parts.append(d_o.to_numpy(np.float32, (f1 - f0) * nfft))
     got = np.concatenate(parts)
-    # different kernels may serve the two sizes (persistent pair kernel vs one frame per slot): same
-    # arithmetic per frame, so the rows agree to float32 rounding of the dB value
+    # different kernels serve the two sizes (one frame per wavefront for the long stream, one frame per
+    # workgroup for the halves): different summation orders, so the rows agree like each agrees with the
+    # oracle -- 1e-3 dB on bins within 50 dB of the frame's peak, 1e-5 of the peak power everywhere
     assert got.shape == one.shape
-    fin = np.isfinite(one)
-    assert np.array_equal(np.isfinite(got), fin)
-    assert np.abs(got[fin] - one[fin]).max() <= 1e-3
+    g2, o2 = got.reshape(frames, nfft).astype(np.float64), one.reshape(frames, nfft).astype(np.float64)
+    strong = o2 >= o2.max(axis=1, keepdims=True) - 50.0
+    assert np.abs(g2 - o2)[strong].max() <= 1e-3
+    gl, ol = 10.0 ** (g2 / 10.0), 10.0 ** (o2 / 10.0)
+    assert (np.abs(gl - ol) <= 1e-5 * ol.max(axis=1, keepdims=True)).all()

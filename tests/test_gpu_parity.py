@@ -941,3 +941,42 @@ def test_pipeline5_zero_run_deviation(sdr, oracle):
     assert set(np.abs(g5[dev]).tolist()) <= {0.0, 0.5}, g5[dev]
     # the deviation is real (if this starts failing the header's exemption 3 can go)
     assert not np.array_equal(g5[dev].astype(np.float64), want[dev].astype(np.float32).astype(np.float64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+def test_fft4096_kernel_variants(sdr, oracle, variant):
+    """The 4096-point / hop-2048 waterfall has four kernels (sdr_fft_plan_set_variant): one frame per
+    workgroup with barrier-separated exchanges, two frames per lane, and one frame per wavefront with
+    four or eight waves per CU (the automatic choice).  Each is held to the oracle
+    (bladerf_main_v1.cpp:183-196 semantics + window + hop) on a stream long enough to select it, with
+    a ragged tail, and an untouched row behind the last frame."""
+    nfft, hop = 4096, 2048
+    frames = 4 * 256 + 37                       # >= 4 frames per CU selects the long-stream kernels
+    n = (frames - 1) * hop + nfft + 1234        # ragged: 1234 samples past the last frame
+    rng = np.random.default_rng(40 + variant)
+    iq = oracle.synth_fm_i16(n, fs=61.44e6, ftone=250e3, dev=2.0e6, amp=1200.0)
+    iq = (iq + rng.integers(-64, 65, iq.size)).astype(np.int16)
+    w = sdr.window("blackman", nfft)
+    plan = sdr.FftPlan(nfft, hop, w)
+    plan.set_variant(variant)
+    assert plan.frame_count(n) == frames
+    d_iq = sdr.DevBuf.from_numpy(iq)
+    d_out = sdr.DevBuf((frames + 1) * nfft * 4)
+    sent = np.full(nfft, 31337.5, np.float32)
+    sdr.capi.check(sdr.capi.lib().sdr_dev_upload(d_out.at(frames * nfft * 4), sent.ctypes.data_as(sdr.capi.C.c_void_p),
+                                                 sdr.capi.C.c_size_t(sent.nbytes)))
+    assert plan.execute_dev(d_iq, n, d_out, frames) == frames
+    sdr.sync()
+    got = d_out.to_numpy(np.float32, (frames + 1) * nfft).reshape(frames + 1, nfft)
+    assert (got[frames] == 31337.5).all()
+    want_db, want_lin = oracle.fft_power_db_i16(iq, nfft, hop, w, linear=True)
+    assert want_db.shape == (frames, nfft)
+    g = got[:frames].astype(np.float64)
+    lin = 10.0 ** (g / 10.0)
+    peak = want_lin.max(axis=1, keepdims=True)
+    assert (np.abs(lin - want_lin) <= 1e-5 * peak).all()
+    strong = want_db >= want_db.max(axis=1, keepdims=True) - 50.0
+    assert np.abs(g - want_db)[strong].max() <= 1e-3
+    with pytest.raises(sdr.SdrError):
+        plan.set_variant(5)

@@ -179,8 +179,20 @@ typedef struct sdr_fir_desc {
                              measured cost model (tiles vs taps per sample) puts it ahead.  Taps
                              smaller than 2^-31 of the largest one are dropped by the fixed point;
                              the discriminator outputs of a stream's start-up transient, where
-                             such taps can decide the angle, are recomputed with float32 taps. */
+                             such taps can decide the angle, are recomputed with float32 taps.
+                             6 = K-split float tiles for SHORT real-input streams (SDR_IN_F32_REAL, any
+                             mode but FM; 4 outputs per lane, 256 threads): the four waves of a workgroup
+                             walk a quarter of the filter each and add their partial sums in a fixed
+                             order -- a quarter of the latency of pipeline 2 where a launch has too few
+                             lane windows to fill the chip (e.g. APT stage 2, bladerf_apt_demod.cpp:744-754,
+                             whose input is a tenth of the capture block).  Chosen automatically from
+                             size_hint. */
     int count_rule;       /* enum sdr_count_rule; 0 = the polyphase_decimate rule */
+    long long size_hint;  /* 0 = unknown; else the input samples a launch will typically see.  Geometry is
+                             chosen for long streams by default; with a hint that says "short" (fewer lane
+                             windows than two waves per SIMD) real-input plans take the K-split kernel
+                             (pipeline 6).  The choice is made once, at plan creation: a plan's outputs do
+                             not depend on how a stream is cut into launches. */
 } sdr_fir_desc;
 
 /* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument
@@ -195,7 +207,7 @@ size_t sdr_fir_out_count(const sdr_fir_plan *plan, size_t n_in);
 int sdr_fir_plan_info(const sdr_fir_plan *plan, int *outputs_per_lane, int *threads,
                       int *lds_bytes);
 /* which kernel the plan runs: 1 = raw-tile, 2 = streaming, 3 = planar, 4 = MFMA float32,
- * 5 = MFMA int8 (see `pipeline`) */
+ * 5 = MFMA int8, 6 = K-split (see `pipeline`) */
 int sdr_fir_plan_kernel(const sdr_fir_plan *plan);
 
 /* One block from zero pre-history, host buffers.  Replaces, fused in one pass,

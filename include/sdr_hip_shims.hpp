@@ -53,11 +53,12 @@ private:
 class FirPlan {
 public:
     FirPlan(const std::vector<double>& taps, int decim, int mode, int input, double scale = 1.0,
-            double mix_fr = 0.0, int count_rule = SDR_COUNT_FLOOR)
+            double mix_fr = 0.0, int count_rule = SDR_COUNT_FLOOR, long long size_hint = 0)
     {
         sdr_fir_desc d{};
         d.input = input; d.mode = mode; d.decim = decim; d.n_taps = (int)taps.size();
         d.taps = taps.data(); d.scale = scale; d.mix_fr = mix_fr; d.count_rule = count_rule;
+        d.size_hint = size_hint;
         check(sdr_fir_plan_create(&d, &p_));
     }
     ~FirPlan() { sdr_fir_plan_destroy(p_); }
@@ -98,7 +99,7 @@ inline std::vector<float> envelope_i16(const std::vector<std::complex<int16_t>>&
 inline std::vector<float> shift_decimate_envelope(const std::vector<float>& x, double fr, int D,
                                                   const std::vector<double>& h)
 {
-    FirPlan plan(h, D, SDR_MODE_ENV, SDR_IN_F32_REAL, 1.0, fr);
+    FirPlan plan(h, D, SDR_MODE_ENV, SDR_IN_F32_REAL, 1.0, fr, SDR_COUNT_FLOOR, (long long)x.size());   // short blocks: K-split kernel
     return plan.run<float, float>(x.data(), x.size());
 }
 
@@ -140,7 +141,7 @@ inline std::vector<uint8_t> fm_audio_u8(const std::vector<float>& x5, const std:
     std::vector<double> hc(lpf_de.size() + lpf_a.size() - 1, 0.0);
     for (size_t i = 0; i < lpf_de.size(); ++i)
         for (size_t j = 0; j < lpf_a.size(); ++j) hc[i + j] += (double)lpf_de[i] * (double)lpf_a[j];
-    FirPlan plan(hc, dec_audio, SDR_MODE_REAL, SDR_IN_F32_REAL, 1.0, 0.0, count_rule);
+    FirPlan plan(hc, dec_audio, SDR_MODE_REAL, SDR_IN_F32_REAL, 1.0, 0.0, count_rule, (long long)x5.size());
     const size_t m = plan.out_count(x5.size());
     std::vector<uint8_t> pcm(m);
     if (m == 0) return pcm;

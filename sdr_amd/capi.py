@@ -33,7 +33,7 @@ class FirDesc(C.Structure):
     _fields_ = [("input", C.c_int), ("mode", C.c_int), ("decim", C.c_int), ("n_taps", C.c_int),
                 ("taps", C.POINTER(C.c_double)), ("scale", C.c_double), ("mix_fr", C.c_double),
                 ("outputs_per_lane", C.c_int), ("threads", C.c_int), ("pipeline", C.c_int),
-                ("count_rule", C.c_int)]
+                ("count_rule", C.c_int), ("size_hint", C.c_longlong)]
 
 
 # per-file compiler flags: the FFT's complex butterflies lose ~12 % when the SLP vectoriser pairs
@@ -180,12 +180,12 @@ class FirPlan:
     """sdr_fir_plan: FIR + decimate (+ mixer) + {IQ, FM discriminator, envelope}."""
 
     def __init__(self, taps, decim, mode=MODE_FM, input=IN_I16_IQ, scale=1.0 / (2.0 * np.pi),
-                 mix_fr=0.0, outputs_per_lane=0, threads=0, pipeline=0, count_rule=COUNT_FLOOR):
+                 mix_fr=0.0, outputs_per_lane=0, threads=0, pipeline=0, count_rule=COUNT_FLOOR, size_hint=0):
         self._taps = np.ascontiguousarray(taps, dtype=np.float64)
         self.mode, self.input, self.decim = mode, input, decim
         d = FirDesc(input, mode, decim, self._taps.size,
                     self._taps.ctypes.data_as(C.POINTER(C.c_double)), scale, mix_fr,
-                    outputs_per_lane, threads, pipeline, count_rule)
+                    outputs_per_lane, threads, pipeline, count_rule, int(size_hint))
         self.h = C.c_void_p()
         check(lib().sdr_fir_plan_create(C.byref(d), C.byref(self.h)))
 
@@ -193,7 +193,7 @@ class FirPlan:
         r, nt, lds = C.c_int(), C.c_int(), C.c_int()
         check(lib().sdr_fir_plan_info(self.h, C.byref(r), C.byref(nt), C.byref(lds)))
         return {"outputs_per_lane": r.value, "threads": nt.value, "lds_bytes": lds.value,
-                "kernel": {1: "raw_tile", 2: "stream", 3: "planar", 4: "mfma", 5: "mfma_i8"}.get(lib().sdr_fir_plan_kernel(self.h), "?")}
+                "kernel": {1: "raw_tile", 2: "stream", 3: "planar", 4: "mfma", 5: "mfma_i8", 6: "ksplit"}.get(lib().sdr_fir_plan_kernel(self.h), "?")}
 
     def out_count(self, n_in):
         return lib().sdr_fir_out_count(self.h, n_in)

@@ -314,21 +314,24 @@ __device__ __forceinline__ void walk_fma(const uint4 (&v)[U], const float (&t)[(
     }
 }
 
+// s_begin / s_count (steps, both even): the part of the window this call walks -- the whole of it
+// (0, ngran / U) everywhere but in fir_ksplit_kernel, whose four waves take a quarter each.
 template <int SPG, int R, bool PAD, bool REALT>
 __device__ __forceinline__ void walk_p(const FirGeom &g, const uint4 *lds4,
-                                       const float *__restrict__ gtab, int tid, float2 (&acc)[R])
+                                       const float *__restrict__ gtab, int tid, float2 (&acc)[R],
+                                       int s_begin = 0, int s_count = -1)
 {
     constexpr int U = Walk<SPG, R>::U;
     constexpr int N = (REALT ? 2 : 1) * Walk<SPG, R>::N;    // floats of taps per step
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
     const uint4 *lane_base = lds4 + tid * (g.q + (PAD ? 1 : 0));
-    const int nstep = g.ngran / U;           // even (host pads)
+    const int nstep = s_count < 0 ? g.ngran / U : s_begin + s_count;           // even (host pads)
     uint4 va[U], vb[U];
     float ta[N], tb[N];
-    walk_load<U, PAD>(va, lane_base, 0, g);
-    walk_taps<N>(ta, gtab);
-    for (int s = 0; s < nstep; s += 2) {
+    walk_load<U, PAD>(va, lane_base, s_begin * U, g);
+    walk_taps<N>(ta, gtab + (size_t)s_begin * N);
+    for (int s = s_begin; s < nstep; s += 2) {
         walk_touch<U, N>(va, ta);
         __builtin_amdgcn_sched_barrier(0);
         walk_load<U, PAD>(vb, lane_base, (s + 1) * U, g);
@@ -346,10 +349,11 @@ __device__ __forceinline__ void walk_p(const FirGeom &g, const uint4 *lds4,
 
 template <int SPG, int R, bool REALT = false>
 __device__ __forceinline__ void walk(const FirGeom &g, const uint4 *lds4,
-                                     const float *__restrict__ gtab, int tid, float2 (&acc)[R])
+                                     const float *__restrict__ gtab, int tid, float2 (&acc)[R],
+                                     int s_begin = 0, int s_count = -1)
 {
-    if (g.pad) walk_p<SPG, R, true, REALT>(g, lds4, gtab, tid, acc);
-    else walk_p<SPG, R, false, REALT>(g, lds4, gtab, tid, acc);
+    if (g.pad) walk_p<SPG, R, true, REALT>(g, lds4, gtab, tid, acc, s_begin, s_count);
+    else walk_p<SPG, R, false, REALT>(g, lds4, gtab, tid, acc, s_begin, s_count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -593,6 +597,70 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
             ynext = ybuf[tid + 1];                 // the last lane's is unused: it emits nothing
         }
         store_outputs<R>(g, outv, tr.ch, m0, acc, ynext, tr.M0 + g.per_tile);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fir_ksplit_kernel: real float input, SHORT streams (plan `pipeline` = 6, or chosen from the plan's
+// size hint).  The streaming kernel above is built for throughput: a lane walks its whole window, and a
+// long filter makes that one dependent chain of T multiply-adds per output behind scalar tap loads.
+// On a stream of a few million samples (the second stage of the APT chain runs at a tenth of the
+// capture rate, bladerf_apt_demod.cpp:744-754) there are fewer such chains than the chip has SIMDs
+// to hide their latency on, and the launch takes as long as ONE chain.  Here a workgroup of four
+// waves owns a tile of only 64 lanes x R outputs, stages its window once, and every wave walks a
+// QUARTER of the window for all 64 lanes; the four partial sums meet in LDS and are added in a fixed
+// order (quarter 0 first), so an output's value does not depend on the tiling or on the shard.  Four
+// times as many, four times shorter chains.  Same byte model as the streaming kernel.
+// LDS: [tile (a_gran float4) | partial sums (4 x 64*R float2)].  No discriminator (the successor of a
+// lane's last output lives in another lane's partial sums; the modes real input is used with --
+// envelope, IQ, real -- do not need it).
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(256)
+fir_ksplit_kernel(const float *__restrict__ in, void *__restrict__ outv,
+                  const float *__restrict__ gtab, const FirGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *tile = (float4 *)smem;
+    float2 *part = (float2 *)(smem + (size_t)g.a_gran * 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = (int)blockIdx.y * g.tiles_per_ch + (int)blockIdx.x;
+    const TileRef tr = tile_ref<IN_REAL>(g, in, t, g.per_tile);
+    for (int a = tid; a < g.a_gran; a += 256) {
+        const int sg0 = sample_granule(g, a);
+        const int sg = sg0 < g.s_gran ? sg0 : g.s_gran - 1;
+        float4 x;
+        if (tr.fast) x = *(const float4 *)(tr.wbase + (unsigned)sg * 16u);
+        else x = fetch_pair_checked<IN_REAL>(g, tr.src, tr.W0 + 4LL * sg);
+        tile[a] = x;
+    }
+    __syncthreads();
+    constexpr int U = Walk<4, R>::U;
+    const int quarter = g.ngran / U / 4;           // even (host pads the window to a multiple of 8 steps)
+    float2 acc[R];
+    walk<4, R, true>(g, (const uint4 *)tile, gtab, lane, acc, wave * quarter, quarter);
+#pragma unroll
+    for (int r = 0; r < R; ++r) part[(wave * 64 + lane) * R + r] = acc[r];
+    __syncthreads();
+    const long long tile_end = tr.M0 + g.per_tile < g.out_end ? tr.M0 + g.per_tile : g.out_end;
+    for (int o = tid; o < 64 * R; o += 256) {
+        const long long m = tr.M0 + o;
+        if (m < g.out_begin || m >= tile_end) continue;
+        const float2 p0 = part[o], p1 = part[64 * R + o], p2 = part[2 * 64 * R + o], p3 = part[3 * 64 * R + o];
+        float2 y = make_float2(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y);
+        if (g.mix_fr != 0.0 && g.mode != SDR_MODE_ENV) {      // the mixer's phasor at the output's own sample
+            const double ph = g.mix_fr * (double)(m * g.D);
+            float2 P;
+            sincospif(2.0f * (float)(ph - rint(ph)), &P.y, &P.x);
+            y = cmulf(y, P);
+        }
+        if (g.mode == SDR_MODE_IQ) {
+            nt_store((float *)((float2 *)outv + tr.ch * g.out_stride + (m - g.out_begin)), y.x, y.y);
+        } else {
+            const float v = g.mode == SDR_MODE_REAL ? y.x : sqrtf(__fmaf_rn(y.x, y.x, y.y * y.y));
+            nt_store((float *)outv + tr.ch * g.out_stride + (m - g.out_begin), v);
+        }
     }
 }
 
@@ -972,7 +1040,8 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 //                                                 bytes of the sample, the low one with bit 7 flipped
 //   tap           h ~ q * 2^-F,  q = d3*2^24 + d2*2^16 + d1*2^8 + d0    balanced digits in [-128, 127]
 //                                                 (q has 31 bits: finer than the float32 taps of the other kernels)
-// Eight byte products per 64 window offsets accumulate in five int32 accumulators, one per weight
+// Seven byte products per 64 window offsets (all but lowest digit x low byte, which lies below 2^-30
+// of full scale) accumulate in four int32 accumulators, one per weight
 // 2^(8w), w = digit + (hi ? 1 : 0), which are combined in float32 once per tile; the +128 of the low
 // bytes comes back as 128 * (sum of the row's digits), combined the same way.  No rounding happens
 // before that last step, and zero samples give exact zeros.
@@ -1146,7 +1215,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 constexpr int UNITS = (NCB / 2) * NSTEPS;
                 b[0][0] = as_i32x4(*(const uint4 *)bbase);
                 b[0][1] = as_i32x4(*(const uint4 *)(bbase + 2 * plane_bytes));
-                i32x4 acc[5];
+                i32x4 acc[4];                                  // weights 2^8 .. 2^32
 #pragma unroll
                 for (int u = 0; u < UNITS; ++u) {
                     const int cb = u / NSTEPS, s = u % NSTEPS;
@@ -1158,35 +1227,36 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     __builtin_amdgcn_sched_barrier(0);
                     if (s == 0) {
 #pragma unroll
-                        for (int w = 0; w < 5; ++w) acc[w] = i32x4{0, 0, 0, 0};
+                        for (int w = 0; w < 4; ++w) acc[w] = i32x4{0, 0, 0, 0};
                     }
                     if (s < NSTEPS - 1 || last_real) {         // wave-uniform
                         const i32x4 xh = b[u & 1][0], xl = b[u & 1][1];
-                        // weight w = digit + (hi ? 1 : 0); no accumulator twice in a row
-                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][0], xl, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][1], xl, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xl, acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][3], xl, acc[3], 0, 0, 0);
-                        acc[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][3], xh, acc[4], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][0], xh, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][1], xh, acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xh, acc[3], 0, 0, 0);
+                        // weight w = digit + (hi ? 1 : 0), accumulator w - 1; the weight-0 product (lowest
+                        // digit x low byte, < 2^-30 of full scale) is left out: seven products, not eight.
+                        // No accumulator twice in a row.
+                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][1], xl, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xl, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][3], xl, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][3], xh, acc[3], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][0], xh, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][1], xh, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xh, acc[2], 0, 0, 0);
                     }
                     if (s == NSTEPS - 1) {
-                        // sum of 2^(8w) * acc[w]: weights 0|1 and 2|3 pair up exactly in int32 (|acc| <
-                        // 2^23), then float32 from the top (balanced digits: the top term carries the
-                        // value, the rest are corrections -- nothing cancels)
+                        // sum of 2^(8w) * acc[w] (the common 2^8 sits in yscale): weights 1|2 and 3|4 pair
+                        // up exactly in int32 (|acc| < 2^23), then one float32 step from the top (balanced
+                        // digits: the top term carries the value, the rest is a correction -- nothing cancels)
                         f32x4 rv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int t01 = acc[1][r] * 256 + acc[0][r], t23 = acc[3][r] * 256 + acc[2][r];
-                            float v = (float)acc[4][r];
-                            v = __fmaf_rn(v, 65536.0f, (float)t23);
-                            v = __fmaf_rn(v, 65536.0f, (float)t01);
-                            rv[r] = v + bias[r];
+                            const int t12 = acc[1][r] * 256 + acc[0][r], t34 = acc[3][r] * 256 + acc[2][r];
+                            rv[r] = __fmaf_rn((float)t34, 65536.0f, (float)t12) + bias[r];
                         }
                         // this tile's set of partial sums is not read before the next phase
-                        part[((((p - 1) & 1) * 4 + wave) * NCB + cb0 + cb) * 64 + lane] = rv;
+                        // within a column block the 128 outputs of each component are stored in output
+                        // order (component 0, then component 1): the finishing lanes then read consecutive
+                        // 16-byte slots (the lane-order layout cost them a four-way bank conflict per read)
+                        part[((((p - 1) & 1) * 4 + wave) * NCB + cb0 + cb) * 64 + (j & 1) * 32 + (j >> 1) * 4 + kq] = rv;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1258,11 +1328,11 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         constexpr int R = NCB / 2;                             // 2 (512-output tile) or 4 (1024)
         constexpr int TILE = 128 * NCB;
         // where those outputs (one float2 / float4: R divides 4) and, for the discriminator, their
-        // successor sit in `part`: output o = 16*grp + i is element i&3 of lane
-        // (i>>2)*16 + 2*(grp&7) + component, column block grp>>3
+        // successor sit in `part`: a column block (128 outputs) is 256 floats, component 0's outputs in
+        // order, then component 1's
         const int o0 = R * ft, o2 = o0 + R < TILE ? o0 + R : TILE - 1;
-        const float *pa = (const float *)(part + (o0 >> 7) * 64 + ((o0 & 15) >> 2) * 16 + 2 * ((o0 >> 4) & 7)) + (o0 & 3);
-        const float *pb = (const float *)(part + (o2 >> 7) * 64 + ((o2 & 15) >> 2) * 16 + 2 * ((o2 >> 4) & 7)) + (o2 & 3);
+        const float *pa = (const float *)part + (o0 >> 7) * 256 + (o0 & 127);
+        const float *pb = (const float *)part + (o2 >> 7) * 256 + (o2 & 127);
         for (int p = 0; p <= n_t + 1; ++p) {
             if (p >= 2 && !(SDR_I8_ABL & 4)) {
                 const int t = i8_tile_index(p - 2);
@@ -1274,7 +1344,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int wv = 0; wv < 4; ++wv) {
-                        const int off = ((((p & 1) * 4 + wv) * NCB) * 64 + c) * 4;
+                        const int off = (((p & 1) * 4 + wv) * NCB) * 256 + c * 128;
                         if constexpr (R == 4) {
                             const float4 q = *(const float4 *)(pa + off);
                             v[c][wv][0] = q.x; v[c][wv][1] = q.y; v[c][wv][2] = q.z; v[c][wv][3] = q.w;
@@ -1358,6 +1428,7 @@ struct sdr_fir_plan {
     bool planar = false;    // fir_planar_kernel (float planes, convert once)
     bool mfma = false;      // fir_mfma_kernel (float planes, Toeplitz GEMM on the matrix cores)
     float4 *d_atab = nullptr;   // its A-operand table
+    bool ksplit = false;    // fir_ksplit_kernel (real input, short streams: taps split over the four waves of a workgroup)
     bool mfma_i8 = false;   // fir_mfma_i8_kernel (byte-split Toeplitz GEMM on the int8 matrix pipe, persistent)
     uint4 *d_atab8 = nullptr;   // its A-operand table (tap digits)
     uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave
@@ -1395,13 +1466,14 @@ struct Geometry { int Tback, Lw4, U, ngran, look, q, pad, s_gran, a_gran, n_inst
 // entries of the coarse mixer phasor table for a tile of s_gran 2-sample granules (even count)
 int ph_hi_entries(int s_gran) { return ((2 * s_gran) / 64 + 2 + 1) & ~1; }
 
-bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *o, bool planar = false, bool mixer = false)
+bool make_geometry(int T, int D, int R, int NT, int spg, bool stream, Geometry *o, bool planar = false, bool mixer = false,
+                   int step_mult = 2)
 {
     if (((long long)D * R) % spg) return false;
     o->Tback = roundup(T - 1, 4);
     o->Lw4 = roundup(o->Tback + D * (R - 1) + 1, 4);
     o->U = (spg * R >= 16) ? 1 : 16 / (spg * R);
-    const int steps = roundup((o->Lw4 / spg + o->U - 1) / o->U, 2);
+    const int steps = roundup((o->Lw4 / spg + o->U - 1) / o->U, step_mult);
     o->ngran = steps * o->U;                  // granules walked (padded with zero taps)
     o->look = o->U;                           // one look-ahead step is loaded, never used
     o->q = D * R / spg;
@@ -1456,6 +1528,15 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         else SDR_I8(3, 4);
 #undef SDR_I8
         return hipGetLastError();
+    }
+    if (p->ksplit) {
+        if constexpr (R == 4) {
+            SDR_OPT_IN(fir_ksplit_kernel<4>);
+            fir_ksplit_kernel<4><<<dim3(tiles, n_ch), 256, p->lds_bytes, st>>>((const float *)in, out, p->d_gtab, g);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;               // plans of this kind always have four outputs per lane
+        }
     }
     if (p->mfma) {
         SDR_OPT_IN(fir_mfma_kernel);
@@ -1579,7 +1660,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->n_taps > 16384) { sdr::set_error("n_taps > 16384 unsupported"); return SDR_EINVAL; }
     if (d->input < SDR_IN_I16_IQ || d->input > SDR_IN_I8_IQ) { sdr::set_error("bad input kind"); return SDR_EINVAL; }
     if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_REAL) { sdr::set_error("bad mode"); return SDR_EINVAL; }
-    if (d->pipeline < 0 || d->pipeline > 5) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
+    if (d->pipeline < 0 || d->pipeline > 6) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
     if (d->count_rule != SDR_COUNT_FLOOR && d->count_rule != SDR_COUNT_AF_SEQ) { sdr::set_error("bad count_rule"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
@@ -1589,7 +1670,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     p->scale = d->scale; p->mix_fr = d->mix_fr; p->count_rule = d->count_rule;
     (void)hipGetDevice(&p->device);
     const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0);
-    if ((d->pipeline == 1 || d->pipeline >= 3) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3, 4 and 5 need int16 input without mixer"); return SDR_EINVAL; }
+    if ((d->pipeline == 1 || (d->pipeline >= 3 && d->pipeline <= 5)) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3, 4 and 5 need int16 input without mixer"); return SDR_EINVAL; }
+    const bool ksplit_possible = d->input == SDR_IN_F32_REAL && d->mode != SDR_MODE_FM;
+    if (d->pipeline == 6 && !ksplit_possible) { delete p; sdr::set_error("pipeline 6 needs real float input and a mode other than FM"); return SDR_EINVAL; }
     // The planar kernel (float planes, convert once) is an explicit choice only: beyond the int8
     // matrix kernel's window it is 8-12 % ahead of the raw tile at D = 8 and 10 but 1.4-1.8x behind
     // at D = 16 and 20 (T = 640..2047, tools/sweep_shapes.py), so the automatic choice there is the raw tile.
@@ -1715,6 +1798,28 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             best = gm; bestR = ncb / 2; bestNT = 256; best_raw = true;   // 256 finishing lanes, two or four outputs each
             p->mfma_i8 = true;
         }
+    }
+    // Short real-input streams (the plan's size hint): when the streaming kernel would put fewer than two
+    // waves on a SIMD its launch lasts as long as one lane's walk over the whole filter; the K-split
+    // kernel cuts that chain in four (APT stage 2 at cfg5's size: 32 -> 12 us)
+    bool want_ksplit = d->pipeline == 6;
+    if (d->pipeline == 0 && ksplit_possible && d->size_hint > 0 && !d->outputs_per_lane && !d->threads && d->n_taps >= 64) {
+        hipDeviceProp_t prop;
+        int ncu = 256;
+        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) ncu = prop.multiProcessorCount;
+        const long long chains = d->size_hint / d->decim / 256;            // waves of 64 lanes x 4 outputs
+        want_ksplit = chains < 8LL * ncu;
+    }
+    if (want_ksplit) {
+        if ((d->outputs_per_lane && d->outputs_per_lane != 4) || (d->threads && d->threads != 256)) { delete p; sdr::set_error("pipeline 6 has 4 outputs per lane and 256 threads"); return SDR_EINVAL; }
+        Geometry gm;
+        bool ok = make_geometry(p->T, p->D, 4, 64, 4, false, &gm, false, false, 8);
+        if (ok) {
+            gm.lds_bytes = gm.a_gran * 16 + 4 * 64 * 4 * 8;
+            ok = gm.lds_bytes <= 160 * 1024;
+        }
+        if (ok) { best = gm; bestR = 4; bestNT = 64; best_raw = false; p->ksplit = true; }
+        else if (d->pipeline == 6) { delete p; sdr::set_error("pipeline 6: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); return SDR_EINVAL; }
     }
     if (!bestR && raw_possible && d->pipeline != 2) {
         const int pref_small[4] = {4, 2, 1, 8}, pref_large[4] = {2, 4, 1, 8};
@@ -1860,7 +1965,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const int F = 30 - e2;                                 // |q| <= 2^30
         std::vector<long long> q(p->T);
         for (int i = 0; i < p->T; ++i) q[i] = std::llround(std::ldexp(d->taps[i], F));
-        p->yscale = (float)std::ldexp(1.0, -(F + 11));         // Q11 samples
+        p->yscale = (float)std::ldexp(1.0, -(F + 11) + 8);     // Q11 samples; the kernel's sums start at weight 2^8
         std::vector<int> rowsum((size_t)4 * 4 * 16, 0);        // [wave][digit][row]
         at8.assign((size_t)4 * kI8Steps * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
         for (int w = 0; w < 4; ++w)
@@ -1894,11 +1999,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * (lane >> 4) + r;
                     const int *rs = &rowsum[(size_t)w * 4 * 16 + row];        // [digit * 16]
-                    const int t01 = 128 * rs[16] * 256 + 128 * rs[0], t23 = 128 * rs[48] * 256 + 128 * rs[32];
-                    float v = 0.0f;
-                    v = std::fmaf(v, 65536.0f, (float)t23);
-                    v = std::fmaf(v, 65536.0f, (float)t01);
-                    bf[r] = v;
+                    // digit d meets the low bytes at weight 2^(8d); weight 0 (digit 0) is not computed
+                    const int t12 = 128 * rs[32] * 256 + 128 * rs[16], t34 = 128 * rs[48];
+                    bf[r] = std::fmaf((float)t34, 65536.0f, (float)t12);
                 }
                 uint4 u;
                 std::memcpy(&u, bf, 16);
@@ -1969,7 +2072,7 @@ extern "C" int sdr_fir_plan_shape(const sdr_fir_plan *p, int *input, int *mode, 
 
 extern "C" int sdr_fir_plan_kernel(const sdr_fir_plan *p)
 {
-    return p ? (p->mfma_i8 ? 5 : (p->mfma ? 4 : (p->planar ? 3 : (p->raw ? 1 : 2)))) : 0;
+    return p ? (p->ksplit ? 6 : (p->mfma_i8 ? 5 : (p->mfma ? 4 : (p->planar ? 3 : (p->raw ? 1 : 2))))) : 0;
 }
 
 extern "C" int sdr_fir_execute_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, void *d_out,

@@ -980,3 +980,57 @@ def test_fft4096_kernel_variants(sdr, oracle, variant):
     assert np.abs(g - want_db)[strong].max() <= 1e-3
     with pytest.raises(sdr.SdrError):
         plan.set_variant(5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,mix", [(511, 15, 2400 / 62400.0), (195, 15, 2400 / 62400.0), (164, 4, 0.0), (64, 7, -0.123),
+                                     (2047, 10, 0.0371)])
+def test_ksplit_kernel_short_real_streams(sdr, oracle, T, D, mix):
+    """Pipeline 6 (fir_ksplit_kernel): real float input, the filter split over the four waves of a
+    workgroup -- the latency kernel for short streams such as APT stage 2
+    (bladerf_apt_demod.cpp:744-754: frequency_shift -> polyphase_decimate -> abs) and the FM audio
+    filters (bladerf_fm_demod.cpp:301-307).  Against the oracle in every mode it supports, on ragged
+    lengths, through a size hint, through time shards (bit-identical: one summation order per output)
+    and through the block hand-off."""
+    rng = np.random.default_rng(T * 31 + D)
+    h = oracle.create_fir_filter(T, min(0.8 / D, 0.9), "hann") * rng.uniform(0.5, 1.0, T)
+    for n in (124_799, 4097, D * 256 * 3, 100, D - 1, 0):
+        xr = (rng.standard_normal(n) * 0.3).astype(np.float32)
+        xs = xr.astype(np.float64).astype(np.complex128)
+        if mix != 0.0 and n:
+            xs = oracle.frequency_shift(xr.astype(np.float64), mix)
+        y = oracle.fir_decimate(xs, D, h) if n >= D else np.zeros(0, np.complex128)
+        for mode, want in ((sdr.MODE_IQ, y), (sdr.MODE_ENV, np.abs(y)), (sdr.MODE_REAL, y.real)):
+            plan = sdr.FirPlan(h, D, mode=mode, input=sdr.IN_F32_REAL, mix_fr=mix, pipeline=6)
+            assert plan.info()["kernel"] == "ksplit"
+            check_linear(plan.execute_host(xr), want, f"ksplit T={T} D={D} n={n} mode={mode}")
+    # chosen from the size hint, not without it, and never for the discriminator
+    small = sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_F32_REAL, mix_fr=mix, size_hint=124_799)
+    big = sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_F32_REAL, mix_fr=mix, size_hint=1 << 28)
+    none = sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_F32_REAL, mix_fr=mix)
+    assert small.info()["kernel"] == "ksplit" and big.info()["kernel"] == "stream" and none.info()["kernel"] == "stream"
+    with pytest.raises(sdr.SdrError):
+        sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_F32_REAL, pipeline=6)
+    with pytest.raises(sdr.SdrError):
+        sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_CF32, pipeline=6)
+    # time shards and block hand-off reproduce the one-piece result bit for bit
+    n = 300_017
+    xr = (rng.standard_normal(n) * 0.3).astype(np.float32)
+    whole = small.execute_host(xr)
+    cnt = whole.size
+    d_all = sdr.DevBuf.from_numpy(xr)
+    parts = []
+    for gidx in range(3):
+        ob, oe = cnt * gidx // 3, cnt * (gidx + 1) // 3
+        lo, hi = max(0, ob * D - (T - 1)), min(n, (oe - 1) * D + 1)
+        d_out = sdr.DevBuf((oe - ob) * 4)
+        small.execute_range_dev(d_all.at(lo * 4), lo, hi - lo, n, ob, oe, d_out)
+        sdr.sync()
+        parts.append(d_out.to_numpy(np.float32, oe - ob))
+    assert np.array_equal(np.concatenate(parts), whole)
+    st = sdr.FirStream(small, 50_000)
+    outs = []
+    for a in range(0, n, 37_123):
+        st.push(xr[a: a + 37_123])
+        outs.append(st.pop())
+    assert np.array_equal(np.concatenate(outs), whole)

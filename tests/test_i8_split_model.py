@@ -1,6 +1,7 @@
 """CPU model of the arithmetic behind FIR plan pipeline 5 (fir_mfma_i8_kernel, sdr_amd/csrc/fir.hip):
 int16 samples as two signed bytes, taps as four balanced base-256 digits of a 31-bit fixed-point
-value, five exact integer accumulators per output, one float32 combination.  The kernel itself is
+value, seven of the eight byte products (the weight-2^0 one is below 2^-30 of full scale and left out)
+in four exact integer accumulators per output, one float32 combination.  The kernel itself is
 checked on the GPU (tests/test_gpu_parity.py); this file pins the scheme's claims -- digit ranges,
 accumulator bounds, exact zeros under zero pre-history, accuracy against the float64 oracle --
 with numpy integers, no GPU."""
@@ -41,22 +42,22 @@ def model_output(x_i, q_digits, F, m, D):
     hi, lo = sample_bytes(xs)
     acc = np.zeros(5, np.int64)
     for d in range(4):
-        acc[d] += int((q_digits[d] * lo).sum())          # weight 2^(8d)
+        if d > 0:
+            acc[d] += int((q_digits[d] * lo).sum())      # weight 2^(8d); the kernel leaves weight 2^0 out
         acc[d + 1] += int((q_digits[d] * hi).sum())      # weight 2^(8(d+1))
     assert np.abs(acc).max() < 2 ** 31
-    bias = np.array([128 * int(q_digits[d].sum()) for d in range(4)] + [0], np.int64)
+    bias = np.array([0] + [128 * int(q_digits[d].sum()) for d in range(1, 4)] + [0], np.int64)
+    dropped = int((q_digits[0] * (lo + 128)).sum())      # what the missing product would have added
     f = np.float32
 
-    def combine(a):                                      # the kernel's float32 sequence
-        t01 = np.int64(a[1]) * 256 + a[0]
-        t23 = np.int64(a[3]) * 256 + a[2]
-        assert abs(int(t01)) < 2 ** 31 and abs(int(t23)) < 2 ** 31
-        v = f(a[4])
-        v = f(np.float64(v) * 65536.0 + np.float64(f(t23)))      # fma: one rounding
-        v = f(np.float64(v) * 65536.0 + np.float64(f(t01)))
-        return v
-    exact = sum(int(acc[w] + bias[w]) << (8 * w) for w in range(5))
-    y32 = f(f(combine(acc) + combine(bias)) * f(np.ldexp(1.0, -(F + 11))))
+    def combine(a):                                      # the kernel's float32 sequence (weights 2^8 .. 2^32)
+        t12 = np.int64(a[2]) * 256 + a[1]
+        t34 = np.int64(a[4]) * 256 + a[3]
+        assert abs(int(t12)) < 2 ** 31 and abs(int(t34)) < 2 ** 31
+        return f(np.float64(f(t34)) * 65536.0 + np.float64(f(t12)))      # fma: one rounding
+    exact = sum(int(acc[w] + bias[w]) << (8 * w) for w in range(5)) + dropped
+    y32 = f(f(combine(acc) + combine(bias)) * f(np.ldexp(1.0, -(F + 11) + 8)))
+    assert abs(dropped) <= 128 * 255 * q_digits.shape[1]                 # < 2^-30 of the 2^45 full-scale sum per tap
     return exact, y32
 
 

@@ -91,7 +91,8 @@ def cfg5(iters):
     h2 = sdr_amd.create_fir_filter(T, 2400 / 62400.0, "hann")
     fr = 2400 / 62400.0
     p1 = sdr_amd.FirPlan(h1, D1, mode=sdr_amd.MODE_FM)
-    p2 = sdr_amd.FirPlan(h2, D2, mode=sdr_amd.MODE_ENV, input=sdr_amd.IN_F32_REAL, mix_fr=fr)
+    p2 = sdr_amd.FirPlan(h2, D2, mode=sdr_amd.MODE_ENV, input=sdr_amd.IN_F32_REAL, mix_fr=fr,
+                         size_hint=p1.out_count(n))          # stage 2 sees a tenth of the block: short-stream geometry
     d_in = sdr_amd.DevBuf(n * 4)
     sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=624e3, ftone=2400.0, dev=17000.0, amp=1800.0, noise_lsb=4, seed=5)
     n6 = p1.out_count(n)

@@ -1070,6 +1070,7 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 // ---------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kI8Steps = 3;        // k steps per matrix wave (12 steps of 64 = windows up to 768 samples)
+constexpr int kI8PartSlots = 66;   // float4 slots of one column block's partial sums (2 components x 32, padded)
 // octets (8 samples) a staging lane fetches ahead per tile: 4 (6 for the 1024-output tile) x 256 x 8 samples
 
 // SDR_MEASUREMENT_BUILD only (sdr_internal.h): 1 no k loop, 2 no staging, 4 no epilogue
@@ -1253,10 +1254,12 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                             rv[r] = __fmaf_rn((float)t34, 65536.0f, (float)t12) + bias[r];
                         }
                         // this tile's set of partial sums is not read before the next phase
-                        // within a column block the 128 outputs of each component are stored in output
-                        // order (component 0, then component 1): the finishing lanes then read consecutive
-                        // 16-byte slots (the lane-order layout cost them a four-way bank conflict per read)
-                        part[((((p - 1) & 1) * 4 + wave) * NCB + cb0 + cb) * 64 + (j & 1) * 32 + (j >> 1) * 4 + kq] = rv;
+                        // within a column block (66 slots of 16 bytes) the 128 outputs of each component are
+                        // stored in output order, component 1 starting at slot 33: the finishing lanes read
+                        // consecutive slots (the lane-order layout cost them a four-way bank conflict per
+                        // read), and the odd component offset keeps these stores down to a two-way conflict,
+                        // which hides behind the store's register transfer
+                        part[((((p - 1) & 1) * 4 + wave) * NCB + cb0 + cb) * kI8PartSlots + (j & 1) * 33 + (j >> 1) * 4 + kq] = rv;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1328,11 +1331,11 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         constexpr int R = NCB / 2;                             // 2 (512-output tile) or 4 (1024)
         constexpr int TILE = 128 * NCB;
         // where those outputs (one float2 / float4: R divides 4) and, for the discriminator, their
-        // successor sit in `part`: a column block (128 outputs) is 256 floats, component 0's outputs in
-        // order, then component 1's
+        // successor sit in `part`: a column block (128 outputs) is kI8PartSlots float4 slots, component
+        // 0's outputs in order from slot 0, component 1's from slot 33
         const int o0 = R * ft, o2 = o0 + R < TILE ? o0 + R : TILE - 1;
-        const float *pa = (const float *)part + (o0 >> 7) * 256 + (o0 & 127);
-        const float *pb = (const float *)part + (o2 >> 7) * 256 + (o2 & 127);
+        const float *pa = (const float *)part + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
+        const float *pb = (const float *)part + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
         for (int p = 0; p <= n_t + 1; ++p) {
             if (p >= 2 && !(SDR_I8_ABL & 4)) {
                 const int t = i8_tile_index(p - 2);
@@ -1344,7 +1347,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int wv = 0; wv < 4; ++wv) {
-                        const int off = (((p & 1) * 4 + wv) * NCB) * 256 + c * 128;
+                        const int off = (((p & 1) * 4 + wv) * NCB) * (4 * kI8PartSlots) + c * (4 * 33);
                         if constexpr (R == 4) {
                             const float4 q = *(const float4 *)(pa + off);
                             v[c][wv][0] = q.x; v[c][wv][1] = q.y; v[c][wv][2] = q.z; v[c][wv][3] = q.w;
@@ -1724,7 +1727,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const double t_valu = std::fmax(0.256, 0.17 + 0.0125 * (double)d->n_taps / (double)d->decim);
         const int Wn = roundup(d->n_taps - 1, 4) + 15 * d->decim + 1;
         const int steps = ((Wn + 63) / 64 + 3) / 4;
-        const bool big = 2 * 4 * (roundup(16 * d->decim * 63 + 256 * steps, 256) + 240) + 65536 <= 160 * 1024;
+        const bool big = 2 * 4 * (roundup(16 * d->decim * 63 + 256 * steps, 256) + 240) + 2 * 4 * 8 * kI8PartSlots * 16 <= 160 * 1024;
         const double per_tile_us = big ? (steps <= 1 ? 1.85 : (steps == 2 ? 2.1 : 3.2))
                                        : (steps <= 1 ? 1.2 : (steps == 2 ? 1.35 : 1.7));
         const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
@@ -1780,7 +1783,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 if (cost < best_cost) { best_cost = cost; best_skew = skew; }
             }
             const int plane = base + best_skew;
-            const int lds = 2 * 4 * plane + 2 * 4 * cand * 1024;   // two tile buffers + two sets of partial sums
+            const int lds = 2 * 4 * plane + 2 * 4 * cand * kI8PartSlots * 16;   // two tile buffers + two sets of partial sums
             if (lds > 160 * 1024 && cand > 4) continue;
             ncb = cand;
             p->plane_bytes = plane;

@@ -57,6 +57,8 @@ struct FirGeom {
     long long tile0;        // first output of tile 0 (multiple of 4)
     long long out_begin;    // outputs written: [out_begin, out_end); out[0] holds out_begin
     long long out_end;
+    long long store_from;   // store_outputs skips outputs below this (= out_begin, or past the start-up outputs
+                            // that fir_mfma_i8_kernel recomputes with float32 taps)
     double mix_fr;          // NCO frequency, cycles per sample (0 = off)
     int D;
     int T;
@@ -190,7 +192,7 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long long j = m0 + r;
-            if (j >= g.out_begin && j < out_end) nt_store((float *)(out + (j - g.out_begin)), y[r].x, y[r].y);
+            if (j >= g.store_from && j < out_end) nt_store((float *)(out + (j - g.out_begin)), y[r].x, y[r].y);
         }
         return;
     }
@@ -209,7 +211,7 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
     }
     float *out = (float *)outv + ch * g.out_stride;
     float *dst = out + (m0 - g.out_begin);
-    const bool whole = (m0 >= g.out_begin) && (m0 + R <= out_end);
+    const bool whole = (m0 >= g.store_from) && (m0 + R <= out_end);
     if (R >= 2 && whole && (((uintptr_t)dst) & (R >= 4 ? 15 : 7)) == 0) {
         if (R == 2) {
             nt_store(dst, v[0], v[1]);
@@ -222,7 +224,7 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long long j = m0 + r;
-            if (j >= g.out_begin && j < out_end) nt_store(dst + r, v[r]);
+            if (j >= g.store_from && j < out_end) nt_store(dst + r, v[r]);
         }
     }
 }
@@ -1073,12 +1075,36 @@ constexpr int kI8Steps = 3;        // k steps per matrix wave (12 steps of 64 = 
 constexpr int kI8PartSlots = 66;   // float4 slots of one column block's partial sums (2 components x 32, padded)
 // octets (8 samples) a staging lane fetches ahead per tile: 4 (6 for the 1024-output tile) x 256 x 8 samples
 
-// SDR_MEASUREMENT_BUILD only (sdr_internal.h): 1 no k loop, 2 no staging, 4 no epilogue
+// SDR_MEASUREMENT_BUILD only (sdr_internal.h): 1 no k loop, 2 no staging, 4 no epilogue, 8 per-wave
+// phase clocks behind the outputs (tools/i8_stamps.py), 16 no accumulator combination, 32 no sample
+// reads inside the k loop
 #ifdef SDR_I8_ABLATE
 #define SDR_I8_ABL SDR_I8_ABLATE
 #else
 #define SDR_I8_ABL 0
 #endif
+
+// bit 8: shader cycles each wave spends working / parked at the per-tile barrier
+struct I8Clock {
+#if SDR_I8_ABL & 8
+    long long busy = 0, wait = 0, t = 0;
+    __device__ __forceinline__ void start() { t = (long long)__builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void arrive() { const long long n = (long long)__builtin_amdgcn_s_memtime(); busy += n - t; t = n; }
+    __device__ __forceinline__ void leave() { const long long n = (long long)__builtin_amdgcn_s_memtime(); wait += n - t; t = n; }
+    __device__ __forceinline__ void flush(void *outv, long long n_out, int phases) const
+    {
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t *d = (uint32_t *)outv + n_out + 64 + 4 * ((long long)blockIdx.x * 16 + (threadIdx.x >> 6));
+            d[0] = (uint32_t)busy; d[1] = (uint32_t)wait; d[2] = (uint32_t)phases; d[3] = 0x51u;
+        }
+    }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void arrive() {}
+    __device__ __forceinline__ void leave() {}
+    __device__ __forceinline__ void flush(void *, long long, int) const {}
+#endif
+};
 
 __device__ __forceinline__ i32x4 as_i32x4(uint4 v) { return __builtin_bit_cast(i32x4, v); }
 
@@ -1169,6 +1195,41 @@ __device__ __forceinline__ void i8_split4(uint4 w, uint32_t &il, uint32_t &ih, u
     qh = __builtin_amdgcn_perm(c23, c01, 0x07060302u);
 }
 
+// The discriminator outputs of a stream's start-up transient, computed with float32 taps by the
+// finishing waves of fir_mfma_i8_kernel while the pipeline fills (they have nothing to finish in
+// its first two phases).  There |y| is small and the taps below the matrix kernel's fixed-point
+// resolution (2^-31 of the largest tap: the numerically-zero taps of a windowed sinc) decide the
+// angle of an output whose other y is exactly zero, which the reference reports as 0 or +-pi by
+// the signs of its zeros.  One wave per output: the lanes share the taps of y[m] and y[m+1],
+// wave-reduce, lane 0 applies the discriminator.  A few dozen outputs per stream start.
+__device__ __forceinline__ void i8_startup_fm_output(const uint32_t *__restrict__ in, float *__restrict__ out,
+                                                     const float *__restrict__ taps, const FirGeom &g,
+                                                     long long m, long long ch, int lane)
+{
+    const uint32_t *src = in + ch * g.in_stride;
+    float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+    const long long n0 = m * g.D, n1 = n0 + g.D;
+    for (int k = lane; k < g.T; k += 64) {
+        const float h = taps[k];
+        const long long s0 = n0 - k, s1 = n1 - k;
+        if (s0 >= g.lo_valid && s0 < g.hi_valid) {
+            const uint32_t w = src[s0];
+            const float xi = g.swap_iq ? hi16(w) : lo16(w), xq = g.swap_iq ? lo16(w) : hi16(w);
+            a0.x = __fmaf_rn(h, xi, a0.x);
+            a0.y = __fmaf_rn(h, xq, a0.y);
+        }
+        if (s1 >= g.lo_valid && s1 < g.hi_valid) {
+            const uint32_t w = src[s1];
+            const float xi = g.swap_iq ? hi16(w) : lo16(w), xq = g.swap_iq ? lo16(w) : hi16(w);
+            a1.x = __fmaf_rn(h, xi, a1.x);
+            a1.y = __fmaf_rn(h, xq, a1.y);
+        }
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) out[ch * g.out_stride + (m - g.out_begin)] = discriminate(a1, a0, g.scale);
+}
+
 // NSTEPS = k steps per matrix wave = ceil(steps in the window / 4).  Steps past the window carry
 // zero taps (the staged tile covers 4*NSTEPS steps, so their sample reads stay inside it); only the
 // last step is skipped by the waves that do not own a real one.
@@ -1176,7 +1237,7 @@ template <int NSTEPS, int NCB>
 __global__ void __launch_bounds__(1024, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
-                   const int plane_bytes, const float yscale)
+                   const int plane_bytes, const float yscale, const float *__restrict__ ftaps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -1185,6 +1246,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     f32x4 *part = (f32x4 *)(smem + 2 * buf_bytes);             // [tile parity][wave][column block][lane]
     // this workgroup's tiles: n_t rounds (the last one may be partial)
     const int n_t = (g.total_tiles - i8_tile_index(0) + (int)gridDim.x - 1) / (int)gridDim.x;
+    I8Clock clk;
 
     if (matrix) {
         // eight matrix waves, two per SIMD: wave (tid / 64) % 4 owns k steps as described above, and
@@ -1207,6 +1269,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // hi plane of component j&1, this lane's group within a column block, this wave's step 0
         const int bofs = (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq + 64 * wave;
         const int cb_bytes = 16 * g.D * 8;                     // between column blocks
+        clk.start();
         for (int p = 0; p <= n_t + 1; ++p) {
             const bool work = p >= 1 && p <= n_t;
             if (work && !(SDR_I8_ABL & 1)) {
@@ -1220,7 +1283,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 #pragma unroll
                 for (int u = 0; u < UNITS; ++u) {
                     const int cb = u / NSTEPS, s = u % NSTEPS;
-                    if (u + 1 < UNITS) {
+                    if (u + 1 < UNITS && !(SDR_I8_ABL & 32)) {
                         const unsigned char *bp = bbase + ((u + 1) / NSTEPS) * cb_bytes + 64 * 4 * ((u + 1) % NSTEPS);
                         b[(u + 1) & 1][0] = as_i32x4(*(const uint4 *)bp);
                         b[(u + 1) & 1][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
@@ -1250,6 +1313,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         f32x4 rv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
+                            if (SDR_I8_ABL & 16) { rv[r] = __int_as_float(acc[0][r] ^ acc[1][r] ^ acc[2][r] ^ acc[3][r]); continue; }
                             const int t12 = acc[1][r] * 256 + acc[0][r], t34 = acc[3][r] * 256 + acc[2][r];
                             rv[r] = __fmaf_rn((float)t34, 65536.0f, (float)t12) + bias[r];
                         }
@@ -1264,7 +1328,9 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            clk.arrive();
             lds_only_barrier();
+            clk.leave();
         }
     } else if (tid < 768) {
         // ================= staging waves: fetch, split, stage =================================
@@ -1311,15 +1377,19 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     put(oct, i8_fetch(tl, 2 * oct, g.s_gran), i8_fetch(tl, 2 * oct + 1, g.s_gran));
             }
             request(p + (NCB > 4 ? 1 : 2), w);
+            clk.arrive();
             lds_only_barrier();
+            clk.leave();
         };
         if constexpr (NCB > 4) {
             // 1024-output tiles take twice as long: one tile ahead gives the same lead, in half the registers
             request(0, w0);
+            clk.start();
             for (int p = 0; p <= n_t + 1; ++p) phase(p, w0);
         } else {
             request(0, w0);
             request(1, w1);
+            clk.start();
             for (int p = 0; p <= n_t + 1; p += 2) {
                 phase(p, w0);
                 if (p + 1 <= n_t + 1) phase(p + 1, w1);
@@ -1336,6 +1406,16 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         const int o0 = R * ft, o2 = o0 + R < TILE ? o0 + R : TILE - 1;
         const float *pa = (const float *)part + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
         const float *pb = (const float *)part + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
+        if (ftaps) {
+            // outputs [out_begin, store_from) of every channel: see i8_startup_fm_output; dealt over the
+            // finishing waves of the whole grid, done before the first tile arrives here
+            const long long n_su = g.store_from - g.out_begin, total = n_su * (g.total_tiles / g.tiles_per_ch);
+            for (long long idx = 4LL * blockIdx.x + (ft >> 6); idx < total; idx += 4LL * gridDim.x) {
+                const long long ch = idx / n_su;
+                i8_startup_fm_output(in, (float *)outv, ftaps, g, g.out_begin + (idx - ch * n_su), ch, ft & 63);
+            }
+        }
+        clk.start();
         for (int p = 0; p <= n_t + 1; ++p) {
             if (p >= 2 && !(SDR_I8_ABL & 4)) {
                 const int t = i8_tile_index(p - 2);
@@ -1367,48 +1447,12 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                                     (((z[1][0] + z[1][1]) + z[1][2]) + z[1][3]) * yscale);
                 store_outputs<R>(g, outv, ch, M0 + (long long)R * ft, y, ynext, M0 + g.per_tile);
             }
+            clk.arrive();
             lds_only_barrier();
+            clk.leave();
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// fir_startup_fm_kernel: the discriminator outputs of a stream's start-up transient, recomputed with
-// float32 taps after fir_mfma_i8_kernel.  There |y| is small and the taps
-// below the matrix kernel's fixed-point resolution (2^-31 of the largest tap: the numerically-zero
-// taps of a windowed sinc) decide the angle of an output whose other y is exactly zero, which the
-// reference reports as 0 or +-pi by the signs of its zeros.  One wave per output: the lanes share
-// the taps of y[m] and y[m+1], wave-reduce, lane 0 applies the discriminator.  A few dozen outputs
-// per stream start.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-fir_startup_fm_kernel(const uint32_t *__restrict__ in, float *__restrict__ out,
-                      const float *__restrict__ taps, const FirGeom g, long long m_begin)
-{
-    const int lane = threadIdx.x;
-    const long long m = m_begin + blockIdx.x, ch = blockIdx.y;
-    const uint32_t *src = in + ch * g.in_stride;
-    float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
-    const long long n0 = m * g.D, n1 = n0 + g.D;
-    for (int k = lane; k < g.T; k += 64) {
-        const float h = taps[k];
-        const long long s0 = n0 - k, s1 = n1 - k;
-        if (s0 >= g.lo_valid && s0 < g.hi_valid) {
-            const uint32_t w = src[s0];
-            const float xi = g.swap_iq ? hi16(w) : lo16(w), xq = g.swap_iq ? lo16(w) : hi16(w);
-            a0.x = __fmaf_rn(h, xi, a0.x);
-            a0.y = __fmaf_rn(h, xq, a0.y);
-        }
-        if (s1 >= g.lo_valid && s1 < g.hi_valid) {
-            const uint32_t w = src[s1];
-            const float xi = g.swap_iq ? hi16(w) : lo16(w), xq = g.swap_iq ? lo16(w) : hi16(w);
-            a1.x = __fmaf_rn(h, xi, a1.x);
-            a1.y = __fmaf_rn(h, xq, a1.y);
-        }
-    }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == 0) out[ch * g.out_stride + (m - g.out_begin)] = discriminate(a1, a0, g.scale);
+    clk.flush(outv, g.out_end - g.out_begin, n_t + 2);
 }
 
 }  // namespace
@@ -1435,7 +1479,7 @@ struct sdr_fir_plan {
     bool mfma_i8 = false;   // fir_mfma_i8_kernel (byte-split Toeplitz GEMM on the int8 matrix pipe, persistent)
     uint4 *d_atab8 = nullptr;   // its A-operand table (tap digits)
     uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave
-    float *d_ftaps = nullptr;   // float32 taps (Q11 folded) for fir_startup_fm_kernel (discriminator plans)
+    float *d_ftaps = nullptr;   // float32 taps (Q11 folded) for i8_startup_fm_output (discriminator plans)
     int plane_bytes = 0;
     float yscale = 1.f;         // its output scale 2^-(F+11)
     sdr_fir_plan *tiny = nullptr;   // automatic choice only: the VALU plan that takes streams shorter than 4 samples
@@ -1522,7 +1566,8 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
     do {                                                                                         \
         SDR_OPT_IN(fir_mfma_i8_kernel<NS, CB>);                                                  \
         fir_mfma_i8_kernel<NS, CB><<<nb, 1024, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
-                                                                  p->plane_bytes, p->yscale);                \
+                                                                  p->plane_bytes, p->yscale,                 \
+                                                                  g.store_from > g.out_begin ? p->d_ftaps : nullptr); \
     } while (0)
         const int ns = (p->ngran + 3) / 4;
         if (p->R == 4) { if (ns <= 1) SDR_I8(1, 8); else if (ns == 2) SDR_I8(2, 8); else SDR_I8(3, 8); }
@@ -1600,6 +1645,12 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.tile0 = out_begin & ~3LL;
     g.out_begin = out_begin;
     g.out_end = out_end;
+    g.store_from = out_begin;
+    if (p->mfma_i8 && p->d_ftaps && p->mode == SDR_MODE_FM && out_begin * p->D < p->T - 1) {
+        // the start-up outputs are computed with float32 taps (i8_startup_fm_output), not by the tiles
+        const long long split = (p->T - 1 + p->D - 1) / p->D + 1;
+        g.store_from = split < out_end ? split : out_end;
+    }
     g.mix_fr = p->mix_fr;
     g.D = p->D; g.T = p->T; g.Tback = p->Tback; g.ngran = p->ngran; g.q = p->q; g.pad = p->pad;
     g.magic = (unsigned)((0x100000000ULL + (unsigned)p->q) / (unsigned)(p->q + 1));
@@ -1628,15 +1679,6 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     }
     if (e != hipSuccess) return sdr::hip_fail(e, what);
     p->lds_opt_in.store(true, std::memory_order_relaxed);
-    if (p->mfma_i8 && p->d_ftaps && p->mode == SDR_MODE_FM && out_begin * p->D < p->T - 1) {
-        // start-up outputs again, with float32 taps (see fir_startup_fm_kernel)
-        long long split = (p->T - 1 + p->D - 1) / p->D + 1;
-        if (split > out_end) split = out_end;
-        fir_startup_fm_kernel<<<dim3((unsigned)(split - out_begin), (unsigned)n_ch), 64, 0, st>>>(
-            (const uint32_t *)base, (float *)out, p->d_ftaps, g, out_begin);
-        e = hipGetLastError();
-        if (e != hipSuccess) return sdr::hip_fail(e, "fir start-up kernel launch");
-    }
     return SDR_OK;
 }
 

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-role phase clocks of fir_mfma_i8_kernel from a measurement build (SDR_I8_ABLATE bit 8): shader
+cycles per tile that each role works / is parked at the barrier.  usage: SDRHIP_LIB=<build> i8_stamps.py [log2n]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sdr_amd  # noqa: E402
+
+log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
+T, D = 511, 10
+sdr_amd.init(0)
+print(sdr_amd.capi.build_info())
+n = 1 << log2n
+d_in = sdr_amd.DevBuf(n * 4 + 64)
+sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=20e6, noise_lsb=8)
+n_out = n // D - 1
+d_out = sdr_amd.DevBuf((n_out + 64 + 4 * 16 * 256 + 64) * 4)
+h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
+p = sdr_amd.FirPlan(h, D, mode=1, pipeline=5)
+p.time_dev(d_in, n, d_out, 40)
+ms = p.time_dev(d_in, n, d_out, 1)
+st = d_out.to_numpy(np.uint32, 4 * 16 * 256, (n_out + 64) * 4).reshape(256, 16, 4).astype(np.float64)
+assert (st[:, :, 3] == 0x51).all(), "no stamps: not a bit-8 measurement build?"
+ph = st[:, :, 2]
+print("kernel ms", ms, "phases per workgroup", ph.min(), ph.max())
+for name, sl in (("matrix", slice(0, 8)), ("staging", slice(8, 12)), ("finishing", slice(12, 16))):
+    busy = (st[:, sl, 0] / ph[:, sl]).ravel()
+    wait = (st[:, sl, 1] / ph[:, sl]).ravel()
+    print("%-9s cycles per phase: working median %.0f (p10 %.0f p90 %.0f)  at the barrier median %.0f (p10 %.0f p90 %.0f)"
+          % (name, np.median(busy), np.percentile(busy, 10), np.percentile(busy, 90),
+             np.median(wait), np.percentile(wait, 10), np.percentile(wait, 90)))
+for w in range(16):
+    print("wave %2d working %.0f waiting %.0f" % (w, np.median(st[:, w, 0] / ph[:, w]), np.median(st[:, w, 1] / ph[:, w])))

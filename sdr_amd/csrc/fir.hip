@@ -182,6 +182,10 @@ __device__ __forceinline__ void nt_store(float *p, float a, float b, float c, fl
 }
 
 template <int R>
+__device__ __forceinline__ void store_values(const FirGeom &g, void *__restrict__ outv, long long ch, long long m0,
+                                             const float (&v)[R], long long out_end);
+
+template <int R>
 __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict__ outv,
                                               long long ch, long long m0, const float2 (&y)[R],
                                               float2 ynext, long long tile_end)
@@ -209,12 +213,20 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
         // below 1e-19 (underflow of the squares) is 0 instead of tiny -- far under the tolerance
         for (int r = 0; r < R; ++r) v[r] = sqrtf(__fmaf_rn(y[r].x, y[r].x, y[r].y * y[r].y));
     }
+    store_values<R>(g, outv, ch, m0, v, out_end);
+}
+
+// the real-valued outputs v[0..R) of lane position m0 (discriminator, envelope, real part)
+template <int R>
+__device__ __forceinline__ void store_values(const FirGeom &g, void *__restrict__ outv, long long ch, long long m0,
+                                             const float (&v)[R], long long out_end)
+{
     float *out = (float *)outv + ch * g.out_stride;
     float *dst = out + (m0 - g.out_begin);
     const bool whole = (m0 >= g.store_from) && (m0 + R <= out_end);
     if (R >= 2 && whole && (((uintptr_t)dst) & (R >= 4 ? 15 : 7)) == 0) {
         if (R == 2) {
-            nt_store(dst, v[0], v[1]);
+            nt_store(dst, v[0], v[R > 1 ? 1 : 0]);
         } else {
 #pragma unroll
             for (int r = 0; r < R; r += 4)
@@ -1043,36 +1055,40 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 //   tap           h ~ q * 2^-F,  q = d3*2^24 + d2*2^16 + d1*2^8 + d0    balanced digits in [-128, 127]
 //                                                 (q has 31 bits: finer than the float32 taps of the other kernels)
 // Seven byte products per 64 window offsets (all but lowest digit x low byte, which lies below 2^-30
-// of full scale) accumulate in four int32 accumulators, one per weight
-// 2^(8w), w = digit + (hi ? 1 : 0), which are combined in float32 once per tile; the +128 of the low
-// bytes comes back as 128 * (sum of the row's digits), combined the same way.  No rounding happens
-// before that last step, and zero samples give exact zeros.
+// of full scale) accumulate in four int32 accumulators, one per weight 2^(8w), w = digit + (hi ? 1 : 0),
+// over the WHOLE window.  The four exact integers of an output are combined in float32 once; the +128
+// of the low bytes comes back as 128 * (sum of the row's digits), combined the same way.  No rounding
+// before that step, zero samples give exact zeros, and an output's bits depend neither on the tile
+// it falls into nor on how the stream is cut into launches or shards.
 // Staging is eight byte permutes per four samples -- no conversions.
 //
-// 1024 lanes in three roles.  Waves 0-7 ("matrix waves", two per SIMD, each pair sharing its k steps
-// and splitting the column blocks) only run k loops: the k range
-// (window offsets, steps of 64) is dealt to them round-robin, wave w owns steps w, w+4, w+8 for all
-// NCB column blocks of the tile (a block = 16 columns = 8 groups of 16 outputs x {I, Q}; NCB = 8,
-// a tile of 1024 outputs, when the LDS holds it, else 4), so its share of the tap matrix (3 steps
-// x 4 digits x 16 B per lane = 48 VGPRs) is loaded once per kernel.  Waves 8-11 ("staging waves")
-// fetch the raw samples ahead (two 512-output tiles or one 1024-output tile), split them and stage
-// the next tile into the other LDS buffer; waves 12-15 ("finishing waves", NCB/2 outputs per lane)
-// finish the previous tile (sum of the four matrix waves' partial results, discriminator /
-// envelope, stores):
-//   phase p:  matrix: k loop of tile p-1    | staging: tile p -> buffer p&1,   | finishing: tile p-2
-//             (buffer (p-1)&1), partial     |          request tile p+2        |   from part[p&1]
-//             sums -> part[(p-1)&1]         |                                  |
+// 512 lanes, two waves per SIMD with 256 registers each, in two roles.  Waves 0-3 ("matrix waves")
+// keep the tap digits of the whole window in registers (12 steps x 4 digits x 16 B per lane = 192
+// VGPRs), take a quarter of the tile's column blocks each (a block = 16 columns = 8 groups of 16
+// outputs x {I, Q}; NCB = 8, a tile of 1024 outputs, when the LDS holds it, else 4) and run nothing
+// but k loops: 84 MFMAs per column block, then one float32 combination.  Waves 4-7 ("helper waves")
+// fetch the raw samples two tiles ahead, split them into byte planes and stage the next tile into
+// the other LDS buffer, then finish the tile before the last (discriminator / envelope, stores):
+//   phase p:  matrix: k loops of tile p-1       | helpers: tile p -> buffer p&1, request tile p+2,
+//             (buffer (p-1)&1) -> ybuf[(p-1)&1]  |          finish tile p-2 from ybuf[p&1]
 //             barrier
+// Why this split (tools/ubench/mfma_valu_overlap.hip): while one wave streams MFMAs, another wave of
+// the same SIMD issues about two plain 32-bit vector instructions per MFMA in its shadow (packed
+// float32 instructions: none -- they share the matrix data path), so a tile costs the MFMAs plus
+// whatever vector work does not fit that shadow.  An earlier form (1024 lanes; the window dealt to
+// four matrix waves per column block, 48 registers of digits each) paid the combination four times
+// per block plus a four-way sum in the finishing waves: 626 vector instructions per SIMD and tile
+// against a shadow of 366, and the tile took twice the matrix time.  This form needs ~390.
 //   A (taps):    lane (i = lane % 16, kq = lane / 16) holds digit d of H[i][64*ks + 16*kq + 0..15],
 //                H[i][k] = q[D*i + Tb - k] (the Toeplitz skew lives here, so sample reads stay aligned)
 //   B (samples): lane (j, kq) holds bytes 16*D*grp + 64*ks + 16*kq + 0..15 of plane (j & 1, hi | lo)
 //   C:           lane (j, kq) holds outputs 4*kq + 0..3 of group grp = 8*cb + j/2, component j & 1
 // (the order of the 64 k values inside a step only has to be the same in A and B).
-// LDS: 2 x [I hi | Q hi | I lo | Q lo] byte planes | 2 x part (4 waves x NCB blocks x 64 lanes x float4).
+// LDS: 2 x [I hi | Q hi | I lo | Q lo] byte planes | 2 x ybuf (NCB blocks x 66 float4).
 // ---------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-constexpr int kI8Steps = 3;        // k steps per matrix wave (12 steps of 64 = windows up to 768 samples)
-constexpr int kI8PartSlots = 66;   // float4 slots of one column block's partial sums (2 components x 32, padded)
+constexpr int kI8MaxSteps = 12;    // k steps of 64: windows up to 768 samples (192 registers of tap digits)
+constexpr int kI8PartSlots = 66;   // float4 slots of one column block's outputs (2 components x 32, padded)
 // octets (8 samples) a staging lane fetches ahead per tile: 4 (6 for the 1024-output tile) x 256 x 8 samples
 
 // SDR_MEASUREMENT_BUILD only (sdr_internal.h): 1 no k loop, 2 no staging, 4 no epilogue, 8 per-wave
@@ -1087,19 +1103,23 @@ constexpr int kI8PartSlots = 66;   // float4 slots of one column block's partial
 // bit 8: shader cycles each wave spends working / parked at the per-tile barrier
 struct I8Clock {
 #if SDR_I8_ABL & 8
-    long long busy = 0, wait = 0, t = 0;
-    __device__ __forceinline__ void start() { t = (long long)__builtin_amdgcn_s_memtime(); }
+    long long busy = 0, wait = 0, t = 0, sec[3] = {0, 0, 0}, ts = 0;
+    __device__ __forceinline__ void start() { t = ts = (long long)__builtin_amdgcn_s_memtime(); }
+    // helper waves: time since the last mark (or the barrier) goes to section i
+    __device__ __forceinline__ void mark(int i) { const long long n = (long long)__builtin_amdgcn_s_memtime(); sec[i] += n - ts; ts = n; }
     __device__ __forceinline__ void arrive() { const long long n = (long long)__builtin_amdgcn_s_memtime(); busy += n - t; t = n; }
-    __device__ __forceinline__ void leave() { const long long n = (long long)__builtin_amdgcn_s_memtime(); wait += n - t; t = n; }
+    __device__ __forceinline__ void leave() { const long long n = (long long)__builtin_amdgcn_s_memtime(); wait += n - t; t = ts = n; }
     __device__ __forceinline__ void flush(void *outv, long long n_out, int phases) const
     {
         if ((threadIdx.x & 63) == 0) {
-            uint32_t *d = (uint32_t *)outv + n_out + 64 + 4 * ((long long)blockIdx.x * 16 + (threadIdx.x >> 6));
+            uint32_t *d = (uint32_t *)outv + n_out + 64 + 8 * ((long long)blockIdx.x * 8 + (threadIdx.x >> 6));
             d[0] = (uint32_t)busy; d[1] = (uint32_t)wait; d[2] = (uint32_t)phases; d[3] = 0x51u;
+            d[4] = (uint32_t)sec[0]; d[5] = (uint32_t)sec[1]; d[6] = (uint32_t)sec[2]; d[7] = 0;
         }
     }
 #else
     __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void arrive() {}
     __device__ __forceinline__ void leave() {}
     __device__ __forceinline__ void flush(void *, long long, int) const {}
@@ -1129,44 +1149,53 @@ __device__ __forceinline__ int i8_tile_index(int n)
 }
 
 struct I8Tile {
-    const uint32_t *base;   // sample 0 of the tile (W0); may point before the buffer: only clamped offsets are dereferenced
-    int lo, hi;             // valid samples of the tile, tile-relative: [lo, hi)
-    bool edge;              // some staged sample is outside [lo, hi)
+    const unsigned char *vbase;   // the tile's first valid sample (inside the caller's buffer; wave-uniform)
+    int lo, hi;                   // valid samples of the tile, tile-relative: [lo, hi)
+    int span4;                    // loads start 0 .. span4 bytes behind vbase: max(4*(hi - 4 - lo), 0)
+    bool edge;                    // some staged sample is outside [lo, hi)
 };
+
+// clamp of a 64-bit difference into [0, n] with scalar 32-bit pieces (a 64-bit signed compare would go
+// through the vector unit)
+__device__ __forceinline__ int i8_clamp_diff(long long d, int n)
+{
+    const int top = (int)(d >> 32);
+    const unsigned low = (unsigned)d;
+    return top < 0 ? 0 : ((top > 0 || low > (unsigned)n) ? n : (int)low);
+}
 
 __device__ __forceinline__ I8Tile i8_tile(const FirGeom &g, const uint32_t *__restrict__ in, int t)
 {
-    const long long ch = t / g.tiles_per_ch;
-    const long long W0 = (g.tile0 + (long long)(t - (int)ch * g.tiles_per_ch) * g.per_tile) * g.D - g.Tback;
-    const long long n = 4LL * g.s_gran;
-    long long lo = g.lo_valid - W0, hi = g.hi_valid - W0;
-    lo = lo < 0 ? 0 : (lo > n ? n : lo);
-    hi = hi > n ? n : (hi < lo ? lo : hi);
+    const int ch = t / g.tiles_per_ch;
+    const long long W0 = (g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile) * g.D - g.Tback;
+    const int n = 4 * g.s_gran;
+    const int lo = i8_clamp_diff(g.lo_valid - W0, n);
+    int hi = i8_clamp_diff(g.hi_valid - W0, n);
+    hi = hi < lo ? lo : hi;
     I8Tile r;
-    r.base = in + ch * g.in_stride + W0;
-    r.lo = (int)lo;
-    r.hi = (int)hi;
+    r.vbase = (const unsigned char *)(in + (long long)ch * g.in_stride + W0 + lo);
+    r.lo = lo;
+    r.hi = hi;
+    r.span4 = 4 * max(hi - 4 - lo, 0);                    // the host refuses streams shorter than 4 samples
     r.edge = lo > 0 || hi < n;
     return r;
 }
 
-__device__ __forceinline__ int i8_clamped(const I8Tile &tl, int rel)
-{
-    const int top = tl.hi - 4 > tl.lo ? tl.hi - 4 : tl.lo;     // the host refuses streams shorter than 4 samples
-    return rel < tl.lo ? tl.lo : (rel > top ? top : rel);
-}
+__device__ __forceinline__ int i8_med3(int x, int lo, int hi) { return min(max(x, lo), hi); }   // v_med3_i32 (lo <= hi)
 
-__device__ __forceinline__ uint4 i8_fetch(const I8Tile &tl, int quad, int n_quads)
+// Four samples from tile-relative sample 4*quad, read at the nearest position inside the valid
+// samples: two vector instructions and a load with a scalar base.
+__device__ __forceinline__ uint4 i8_fetch(const I8Tile &tl, int quad)
 {
-    quad = quad < n_quads ? quad : n_quads - 1;
-    return *(const uint4 *)(tl.base + i8_clamped(tl, 4 * quad));
+    const int off = i8_med3(16 * quad - 4 * tl.lo, 0, tl.span4);
+    return *(const uint4 *)(tl.vbase + (unsigned)off);
 }
 
 // edge tiles: w was loaded at the clamped position; pick / zero the samples the quad asked for
-__device__ __forceinline__ uint4 i8_repair(const I8Tile &tl, int quad, int n_quads, uint4 w)
+__device__ __forceinline__ uint4 i8_repair(const I8Tile &tl, int quad, uint4 w)
 {
-    quad = quad < n_quads ? quad : n_quads - 1;
-    const int rel = 4 * quad, at = i8_clamped(tl, rel);
+    const int rel = 4 * quad;
+    const int at = tl.lo + (i8_med3(16 * quad - 4 * tl.lo, 0, tl.span4) >> 2);
     const uint32_t e[4] = {w.x, w.y, w.z, w.w};
     uint32_t o[4];
 #pragma unroll
@@ -1230,100 +1259,151 @@ __device__ __forceinline__ void i8_startup_fm_output(const uint32_t *__restrict_
     if (lane == 0) out[ch * g.out_stride + (m - g.out_begin)] = discriminate(a1, a0, g.scale);
 }
 
-// NSTEPS = k steps per matrix wave = ceil(steps in the window / 4).  Steps past the window carry
-// zero taps (the staged tile covers 4*NSTEPS steps, so their sample reads stay inside it); only the
-// last step is skipped by the waves that do not own a real one.
-template <int NSTEPS, int NCB>
-__global__ void __launch_bounds__(1024, 1)
+// Finishing of tile number n of this workgroup (computed in the previous phase, outputs in ybuf[par]):
+// finishing lane F takes outputs RH*F .. RH*F + RH-1 of the tile and, for the discriminator, their
+// successor.  A column block (128 outputs) is kI8PartSlots float4 slots, component 0's outputs in order
+// from slot 0, component 1's from slot 33.
+template <int RH, int NCB>
+__device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ outv, const float *ybuf, int par, int F, int n)
+{
+    constexpr int TILE = 128 * NCB;
+    const int o0 = RH * F, o2 = o0 + RH < TILE ? o0 + RH : TILE - 1;
+    const float *pa = ybuf + par * NCB * (4 * kI8PartSlots) + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
+    const float *pb = ybuf + par * NCB * (4 * kI8PartSlots) + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
+    const int t = i8_tile_index(n);
+    const int ch = t / g.tiles_per_ch;
+    const long long M0 = g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile;
+    float2 y[RH], ynext;
+    if constexpr (RH == 4) {
+        const float4 qi = *(const float4 *)pa, qq = *(const float4 *)(pa + 4 * 33);
+        y[0] = make_float2(qi.x, qq.x); y[1] = make_float2(qi.y, qq.y);
+        y[2] = make_float2(qi.z, qq.z); y[3] = make_float2(qi.w, qq.w);
+    } else if constexpr (RH == 2) {
+        const float2 qi = *(const float2 *)pa, qq = *(const float2 *)(pa + 4 * 33);
+        y[0] = make_float2(qi.x, qq.x); y[1] = make_float2(qi.y, qq.y);
+    } else {
+        y[0] = make_float2(pa[0], pa[4 * 33]);
+    }
+    ynext = make_float2(pb[0], pb[4 * 33]);
+    store_outputs<RH>(g, outv, ch, M0 + (long long)o0, y, ynext, M0 + g.per_tile);
+}
+
+// NS = k steps of the window, rounded up to a multiple of four (steps past the window carry zero taps
+// and are skipped; the staged tile covers NS steps, so no sample read leaves it).
+template <int NS, int NCB>
+__global__ void __launch_bounds__(512, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
                    const int plane_bytes, const float yscale, const float *__restrict__ ftaps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const bool matrix = tid < 512;
+    const bool matrix = tid < 256;
     const int buf_bytes = 4 * plane_bytes;
-    f32x4 *part = (f32x4 *)(smem + 2 * buf_bytes);             // [tile parity][wave][column block][lane]
+    f32x4 *ybuf = (f32x4 *)(smem + 2 * buf_bytes);             // [tile parity][column block][kI8PartSlots]
     // this workgroup's tiles: n_t rounds (the last one may be partial)
     const int n_t = (g.total_tiles - i8_tile_index(0) + (int)gridDim.x - 1) / (int)gridDim.x;
+    // phases: tile t is staged in phase t, multiplied in t+1, finished in t+2; an even count, so that
+    // the helper waves' loop over their two register sets has no conditional half
+    const int n_ph = (n_t + 3) & ~1;
     I8Clock clk;
 
     if (matrix) {
-        // eight matrix waves, two per SIMD: wave (tid / 64) % 4 owns k steps as described above, and
-        // the two waves with the same steps take one half of the tile's column blocks each
-        const int wave = (tid >> 6) & 3, lane = tid & 63;
-        const int cb0 = (tid >> 8) * (NCB / 2);
+        // four matrix waves, one per SIMD; wave w takes column blocks CBW*w .. CBW*w + CBW-1 of every tile
+        // through the whole window, so an output is one exact integer sum: its value depends neither
+        // on the tile it falls into nor on the shard
+        constexpr int CBW = NCB / 4;
+        const int wave = tid >> 6, lane = tid & 63;
         const int j = lane & 15, kq = lane >> 4;
-        const bool last_real = wave + 4 * (NSTEPS - 1) < g.ngran;   // does this wave own a real last step?
-        // 128 * (sum of this wave's digits of each output row), combined over the digits exactly as the
-        // accumulators are below: it undoes the -128 of the low bytes, and because the combination
-        // is the same sequence of float32 operations on the negated integers, zero samples still
-        // give an exact zero
-        const f32x4 bias = __builtin_bit_cast(f32x4, btab[wave * 64 + lane]);
-        // this wave's share of the tap matrix, resident for the whole kernel
-        i32x4 a[NSTEPS][4];
+        // the tap digits of the whole window, resident for the whole kernel.  Twelve steps x four digits
+        // would be 192 registers and leave no room for the epilogue: the lowest digit, which only one of
+        // the seven products reads, then lives in LDS and is fetched with the samples (144 registers).
+        constexpr bool A0_LDS = NS > 8;
+        i32x4 a[NS][4];
+        uint4 *a0lds = (uint4 *)(ybuf + 2 * NCB * kI8PartSlots);
 #pragma unroll
-        for (int s = 0; s < NSTEPS; ++s)
+        for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
-            for (int d = 0; d < 4; ++d) a[s][d] = as_i32x4(atab[((wave * kI8Steps + s) * 4 + d) * 64 + lane]);
-        // hi plane of component j&1, this lane's group within a column block, this wave's step 0
-        const int bofs = (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq + 64 * wave;
+            for (int d = 0; d < 4; ++d) {
+                if (A0_LDS && d == 0) { if (wave == 0) a0lds[ks * 64 + lane] = atab[(ks * 4) * 64 + lane]; }
+                else a[ks][d] = as_i32x4(atab[(ks * 4 + d) * 64 + lane]);
+            }
+        // 128 * (sum of the row's digits), combined over the digits exactly as the accumulators are
+        // below: it undoes the -128 of the low bytes, and because the combination is the same sequence
+        // of float32 operations on the negated integers, zero samples still give an exact zero
+        const f32x4 bias = __builtin_bit_cast(f32x4, btab[lane]);
+        // hi plane of component j&1, this lane's group within a column block, step 0
+        const int bofs = (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq + CBW * wave * (16 * g.D * 8);
         const int cb_bytes = 16 * g.D * 8;                     // between column blocks
+        // each matrix wave also finishes its own quarter of the tile before the last (R outputs per lane).
+        // Measured alternatives, all within 2 %: finishing in the helper waves (they are then the longer
+        // role), half in each, and its arithmetic interleaved with the MFMAs by sched_group_barrier --
+        // MFMA and vector time of a SIMD add up whichever wave issues them.
+        constexpr int R = NCB / 2;
         clk.start();
-        for (int p = 0; p <= n_t + 1; ++p) {
-            const bool work = p >= 1 && p <= n_t;
-            if (work && !(SDR_I8_ABL & 1)) {
-                const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs + cb0 * cb_bytes;
-                // units of (column block, step), samples requested one unit ahead
-                i32x4 b[2][2];                                 // [buffer][hi, lo]
-                constexpr int UNITS = (NCB / 2) * NSTEPS;
-                b[0][0] = as_i32x4(*(const uint4 *)bbase);
-                b[0][1] = as_i32x4(*(const uint4 *)(bbase + 2 * plane_bytes));
+        for (int p = 0; p < n_ph; ++p) {
+            // the tile before the last
+            if (p >= 2 && p - 2 < n_t && !(SDR_I8_ABL & 4))
+                i8_finish<R, NCB>(g, outv, (const float *)ybuf, p & 1, tid, p - 2);
+            clk.mark(2);
+            const bool work = p >= 1 && p <= n_t && !(SDR_I8_ABL & 1);
+            if (work) {
+                const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs;
+                // units of (column block, step), samples requested two units ahead
+                constexpr int UNITS = CBW * NS;
+                i32x4 b[3][3];                                 // [buffer][hi, lo, lowest tap digit]
+#pragma unroll
+                for (int u = 0; u < 2 && u < UNITS; ++u) {
+                    const unsigned char *bp = bbase + (u / NS) * cb_bytes + 64 * (u % NS);
+                    b[u][0] = as_i32x4(*(const uint4 *)bp);
+                    b[u][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
+                    if (A0_LDS) b[u][2] = as_i32x4(a0lds[(u % NS) * 64 + lane]);
+                }
                 i32x4 acc[4];                                  // weights 2^8 .. 2^32
 #pragma unroll
                 for (int u = 0; u < UNITS; ++u) {
-                    const int cb = u / NSTEPS, s = u % NSTEPS;
-                    if (u + 1 < UNITS && !(SDR_I8_ABL & 32)) {
-                        const unsigned char *bp = bbase + ((u + 1) / NSTEPS) * cb_bytes + 64 * 4 * ((u + 1) % NSTEPS);
-                        b[(u + 1) & 1][0] = as_i32x4(*(const uint4 *)bp);
-                        b[(u + 1) & 1][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
+                    const int cb = u / NS, ks = u % NS;
+                    if (u + 2 < UNITS && !(SDR_I8_ABL & 32)) {
+                        const unsigned char *bp = bbase + ((u + 2) / NS) * cb_bytes + 64 * ((u + 2) % NS);
+                        b[(u + 2) % 3][0] = as_i32x4(*(const uint4 *)bp);
+                        b[(u + 2) % 3][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
+                        if (A0_LDS) b[(u + 2) % 3][2] = as_i32x4(a0lds[((u + 2) % NS) * 64 + lane]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (s == 0) {
+                    if (ks == 0) {
 #pragma unroll
                         for (int w = 0; w < 4; ++w) acc[w] = i32x4{0, 0, 0, 0};
                     }
-                    if (s < NSTEPS - 1 || last_real) {         // wave-uniform
-                        const i32x4 xh = b[u & 1][0], xl = b[u & 1][1];
+                    if (ks < NS - 3 || ks < g.ngran) {         // wave-uniform
+                        const i32x4 xh = b[u % 3][0], xl = b[u % 3][1];
                         // weight w = digit + (hi ? 1 : 0), accumulator w - 1; the weight-0 product (lowest
                         // digit x low byte, < 2^-30 of full scale) is left out: seven products, not eight.
                         // No accumulator twice in a row.
-                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][1], xl, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xl, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][3], xl, acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][3], xh, acc[3], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][0], xh, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][1], xh, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][2], xh, acc[2], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][1], xl, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xl, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xl, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xh, acc[3], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0_LDS ? b[u % 3][2] : a[ks][0], xh, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][1], xh, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xh, acc[2], 0, 0, 0);
                     }
-                    if (s == NSTEPS - 1) {
-                        // sum of 2^(8w) * acc[w] (the common 2^8 sits in yscale): weights 1|2 and 3|4 pair
-                        // up exactly in int32 (|acc| < 2^23), then one float32 step from the top (balanced
-                        // digits: the top term carries the value, the rest is a correction -- nothing cancels)
+                    if (ks == NS - 1) {
+                        // y = yscale * sum of 2^(8w) * acc[w] (the common 2^8 sits in yscale): the only
+                        // floating-point step, a fixed sequence on exact integers.  Balanced digits: the
+                        // top term carries the value, the rest is a correction -- nothing cancels.
                         f32x4 rv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if (SDR_I8_ABL & 16) { rv[r] = __int_as_float(acc[0][r] ^ acc[1][r] ^ acc[2][r] ^ acc[3][r]); continue; }
-                            const int t12 = acc[1][r] * 256 + acc[0][r], t34 = acc[3][r] * 256 + acc[2][r];
-                            rv[r] = __fmaf_rn((float)t34, 65536.0f, (float)t12) + bias[r];
+                            const float lo = __fmaf_rn((float)acc[1][r], 256.0f, (float)acc[0][r]);
+                            const float hi = __fmaf_rn((float)acc[3][r], 256.0f, (float)acc[2][r]);
+                            rv[r] = (__fmaf_rn(hi, 65536.0f, lo) + bias[r]) * yscale;
                         }
-                        // this tile's set of partial sums is not read before the next phase
                         // within a column block (66 slots of 16 bytes) the 128 outputs of each component are
-                        // stored in output order, component 1 starting at slot 33: the finishing lanes read
-                        // consecutive slots (the lane-order layout cost them a four-way bank conflict per
-                        // read), and the odd component offset keeps these stores down to a two-way conflict,
-                        // which hides behind the store's register transfer
-                        part[((((p - 1) & 1) * 4 + wave) * NCB + cb0 + cb) * kI8PartSlots + (j & 1) * 33 + (j >> 1) * 4 + kq] = rv;
+                        // stored in output order, component 1 starting at slot 33: the helper lanes read
+                        // consecutive slots, and the odd component offset keeps these stores down to a
+                        // two-way bank conflict, which hides behind the store's register transfer
+                        ybuf[(((p - 1) & 1) * NCB + CBW * wave + cb) * kI8PartSlots + (j & 1) * 33 + (j >> 1) * 4 + kq] = rv;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1332,15 +1412,23 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             lds_only_barrier();
             clk.leave();
         }
-    } else if (tid < 768) {
-        // ================= staging waves: fetch, split, stage =================================
-        const int st = tid - 512;                              // 0..255
+    } else {
+        // ================= helper waves: stage tile p, request tile p+2 ===========================
+        const int st = tid - 256;                              // 0..255
         const int cI = g.swap_iq ? 1 : 0;                      // Q-first input swaps the component planes
         const int n_oct = (g.s_gran + 1) / 2;                  // octets per tile
+        if (ftaps) {
+            // outputs [out_begin, store_from) of every channel: see i8_startup_fm_output; dealt over the
+            // helper waves of the whole grid, done before the first tile is finished
+            const long long n_su = g.store_from - g.out_begin, total = n_su * (g.total_tiles / g.tiles_per_ch);
+            for (long long idx = 4LL * blockIdx.x + (st >> 6); idx < total; idx += 4LL * gridDim.x) {
+                const long long ch = idx / n_su;
+                i8_startup_fm_output(in, (float *)outv, ftaps, g, g.out_begin + (idx - ch * n_su), ch, st & 63);
+            }
+        }
         // raw samples of two tiles travel at any time: set p&1 holds tile p until it is staged in
-        // phase p and is then refilled with tile p+2 (one tile ahead did not cover the HBM latency).
-        // These waves issue no stores, so waiting for a set never waits for anything else.
-        constexpr int kI8Pre = NCB > 4 ? 6 : 4;
+        // phase p and is then refilled with tile p+2
+        constexpr int kI8Pre = NCB > 4 ? 6 : 4;                // octets per lane and tile held in registers
         uint4 w0[kI8Pre][2], w1[kI8Pre][2];
         auto request = [&](int n, uint4 (&w)[kI8Pre][2]) {     // n-th tile of this workgroup
             // unconditional (past the end: the last tile again, unused): a skipped request would make
@@ -1350,17 +1438,16 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 #pragma unroll
             for (int k = 0; k < kI8Pre; ++k)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) w[k][h] = i8_fetch(tl, 2 * (256 * k + st) + h, g.s_gran);
+                for (int h = 0; h < 2; ++h) w[k][h] = i8_fetch(tl, 2 * (256 * k + st) + h);
         };
         auto phase = [&](int p, uint4 (&w)[kI8Pre][2]) {
-            if (p < n_t && !(SDR_I8_ABL & 2)) {
+            // (past the last tile: the last one again, into a buffer nobody reads any more -- a skipped
+            // staging would leave the set's loads pending on one path into the request below, and hipcc
+            // would then wait for every outstanding load, the other set's included, on all paths)
+            if (!(SDR_I8_ABL & 2)) {
                 unsigned char *buf = smem + (p & 1) * buf_bytes;
-                const I8Tile tl = i8_tile(g, in, i8_tile_index(p));
+                const I8Tile tl = i8_tile(g, in, i8_tile_index(p < n_t ? p : n_t - 1));
                 auto put = [&](int oct, uint4 q0, uint4 q1) {
-                    if (tl.edge) {                             // wave-uniform
-                        q0 = i8_repair(tl, 2 * oct, g.s_gran, q0);
-                        q1 = i8_repair(tl, 2 * oct + 1, g.s_gran, q1);
-                    }
                     uint32_t il[2], ih[2], ql[2], qh[2];
                     i8_split4(q0, il[0], ih[0], ql[0], qh[0]);
                     i8_split4(q1, il[1], ih[1], ql[1], qh[1]);
@@ -1370,89 +1457,41 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     *(uint2 *)(dst + (2 + cI) * plane_bytes) = make_uint2(il[0], il[1]);
                     *(uint2 *)(dst + (3 - cI) * plane_bytes) = make_uint2(ql[0], ql[1]);
                 };
+                // two copies of the loop, not one with a conditional repair inside: a value that is either
+                // the loaded quad or its repaired form becomes a phi of single registers, which cannot
+                // share the load's register tuple, and hipcc then copies every quad (after waiting for
+                // it) at the end of each phase -- the end of all prefetching
+                if (tl.edge) {                                 // wave-uniform
 #pragma unroll
-                for (int k = 0; k < kI8Pre; ++k)
-                    if (256 * k + st < n_oct) put(256 * k + st, w[k][0], w[k][1]);
-                for (int oct = 256 * kI8Pre + st; oct < n_oct; oct += 256)     // very wide tiles only
-                    put(oct, i8_fetch(tl, 2 * oct, g.s_gran), i8_fetch(tl, 2 * oct + 1, g.s_gran));
+                    for (int k = 0; k < kI8Pre; ++k)
+                        if (256 * k + st < n_oct)
+                            put(256 * k + st, i8_repair(tl, 2 * (256 * k + st), w[k][0]), i8_repair(tl, 2 * (256 * k + st) + 1, w[k][1]));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kI8Pre; ++k)
+                        if (256 * k + st < n_oct) put(256 * k + st, w[k][0], w[k][1]);
+                }
+                for (int oct = 256 * kI8Pre + st; oct < n_oct; oct += 256) {   // very wide tiles only
+                    uint4 q0 = i8_fetch(tl, 2 * oct), q1 = i8_fetch(tl, 2 * oct + 1);
+                    put(oct, i8_repair(tl, 2 * oct, q0), i8_repair(tl, 2 * oct + 1, q1));
+                }
             }
-            request(p + (NCB > 4 ? 1 : 2), w);
+            clk.mark(0);
+            request(p + 2, w);
+            clk.mark(1);
             clk.arrive();
             lds_only_barrier();
             clk.leave();
         };
-        if constexpr (NCB > 4) {
-            // 1024-output tiles take twice as long: one tile ahead gives the same lead, in half the registers
-            request(0, w0);
-            clk.start();
-            for (int p = 0; p <= n_t + 1; ++p) phase(p, w0);
-        } else {
-            request(0, w0);
-            request(1, w1);
-            clk.start();
-            for (int p = 0; p <= n_t + 1; p += 2) {
-                phase(p, w0);
-                if (p + 1 <= n_t + 1) phase(p + 1, w1);
-            }
-        }
-    } else {
-        // ================= finishing waves: partial sums -> epilogue -> stores ==================
-        const int ft = tid - 768;                              // 0..255: outputs R*ft .. R*ft+R-1 of the tile
-        constexpr int R = NCB / 2;                             // 2 (512-output tile) or 4 (1024)
-        constexpr int TILE = 128 * NCB;
-        // where those outputs (one float2 / float4: R divides 4) and, for the discriminator, their
-        // successor sit in `part`: a column block (128 outputs) is kI8PartSlots float4 slots, component
-        // 0's outputs in order from slot 0, component 1's from slot 33
-        const int o0 = R * ft, o2 = o0 + R < TILE ? o0 + R : TILE - 1;
-        const float *pa = (const float *)part + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
-        const float *pb = (const float *)part + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
-        if (ftaps) {
-            // outputs [out_begin, store_from) of every channel: see i8_startup_fm_output; dealt over the
-            // finishing waves of the whole grid, done before the first tile arrives here
-            const long long n_su = g.store_from - g.out_begin, total = n_su * (g.total_tiles / g.tiles_per_ch);
-            for (long long idx = 4LL * blockIdx.x + (ft >> 6); idx < total; idx += 4LL * gridDim.x) {
-                const long long ch = idx / n_su;
-                i8_startup_fm_output(in, (float *)outv, ftaps, g, g.out_begin + (idx - ch * n_su), ch, ft & 63);
-            }
-        }
+        request(0, w0);
+        request(1, w1);
         clk.start();
-        for (int p = 0; p <= n_t + 1; ++p) {
-            if (p >= 2 && !(SDR_I8_ABL & 4)) {
-                const int t = i8_tile_index(p - 2);
-                const long long ch = t / g.tiles_per_ch;
-                const long long M0 = g.tile0 + (long long)(t - (int)ch * g.tiles_per_ch) * g.per_tile;
-                float v[2][4][R];                              // [component][wave][output]
-                float z[2][4];                                 // the successor
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int wv = 0; wv < 4; ++wv) {
-                        const int off = (((p & 1) * 4 + wv) * NCB) * (4 * kI8PartSlots) + c * (4 * 33);
-                        if constexpr (R == 4) {
-                            const float4 q = *(const float4 *)(pa + off);
-                            v[c][wv][0] = q.x; v[c][wv][1] = q.y; v[c][wv][2] = q.z; v[c][wv][3] = q.w;
-                        } else {
-                            const float2 q = *(const float2 *)(pa + off);
-                            v[c][wv][0] = q.x; v[c][wv][1] = q.y;
-                        }
-                        z[c][wv] = pb[off];
-                    }
-                // one summation order for every output; then the power-of-two scale
-                float2 y[R], ynext;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    y[r] = make_float2((((v[0][0][r] + v[0][1][r]) + v[0][2][r]) + v[0][3][r]) * yscale,
-                                       (((v[1][0][r] + v[1][1][r]) + v[1][2][r]) + v[1][3][r]) * yscale);
-                ynext = make_float2((((z[0][0] + z[0][1]) + z[0][2]) + z[0][3]) * yscale,
-                                    (((z[1][0] + z[1][1]) + z[1][2]) + z[1][3]) * yscale);
-                store_outputs<R>(g, outv, ch, M0 + (long long)R * ft, y, ynext, M0 + g.per_tile);
-            }
-            clk.arrive();
-            lds_only_barrier();
-            clk.leave();
+        for (int p = 0; p < n_ph; p += 2) {
+            phase(p, w0);
+            phase(p + 1, w1);
         }
     }
-    clk.flush(outv, g.out_end - g.out_begin, n_t + 2);
+    clk.flush(outv, g.out_end - g.out_begin, n_ph);
 }
 
 }  // namespace
@@ -1565,15 +1604,15 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
 #define SDR_I8(NS, CB)                                                                           \
     do {                                                                                         \
         SDR_OPT_IN(fir_mfma_i8_kernel<NS, CB>);                                                  \
-        fir_mfma_i8_kernel<NS, CB><<<nb, 1024, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
+        fir_mfma_i8_kernel<NS, CB><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale,                 \
                                                                   g.store_from > g.out_begin ? p->d_ftaps : nullptr); \
     } while (0)
         const int ns = (p->ngran + 3) / 4;
-        if (p->R == 4) { if (ns <= 1) SDR_I8(1, 8); else if (ns == 2) SDR_I8(2, 8); else SDR_I8(3, 8); }
-        else if (ns <= 1) SDR_I8(1, 4);
-        else if (ns == 2) SDR_I8(2, 4);
-        else SDR_I8(3, 4);
+        if (p->R == 4) { if (ns <= 1) SDR_I8(4, 8); else if (ns == 2) SDR_I8(8, 8); else SDR_I8(12, 8); }
+        else if (ns <= 1) SDR_I8(4, 4);
+        else if (ns == 2) SDR_I8(8, 4);
+        else SDR_I8(12, 4);
 #undef SDR_I8
         return hipGetLastError();
     }
@@ -1769,7 +1808,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const double t_valu = std::fmax(0.256, 0.17 + 0.0125 * (double)d->n_taps / (double)d->decim);
         const int Wn = roundup(d->n_taps - 1, 4) + 15 * d->decim + 1;
         const int steps = ((Wn + 63) / 64 + 3) / 4;
-        const bool big = 2 * 4 * (roundup(16 * d->decim * 63 + 256 * steps, 256) + 240) + 2 * 4 * 8 * kI8PartSlots * 16 <= 160 * 1024;
+        const bool big = 2 * 4 * (roundup(16 * d->decim * 63 + 256 * steps, 256) + 240) + 2 * 8 * kI8PartSlots * 16 + (steps > 2 ? 12 * 1024 : 0) <= 160 * 1024;
         const double per_tile_us = big ? (steps <= 1 ? 1.85 : (steps == 2 ? 2.1 : 3.2))
                                        : (steps <= 1 ? 1.2 : (steps == 2 ? 1.35 : 1.7));
         const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
@@ -1786,13 +1825,13 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->pipeline == 5 || auto_i8) {
         bool fits = true;
         // byte-split Toeplitz GEMM: 1024 or 512 outputs per tile, k steps of 64 dealt to 4 matrix waves
-        if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 chooses its own geometry (1024 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
+        if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 chooses its own geometry (512 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
         Geometry gm{};
         gm.Tback = roundup(p->T - 1, 4);
         const int W = gm.Tback + 15 * p->D + 1;
         const int nks = (W + 63) / 64;
-        if (nks > 4 * kI8Steps) {
-            if (!auto_i8) { sdr::set_error("pipeline 5: window of %d samples exceeds %d (decim=%d taps=%d)", W, 64 * 4 * kI8Steps, p->D, p->T); delete p; return SDR_EINVAL; }
+        if (nks > kI8MaxSteps) {
+            if (!auto_i8) { sdr::set_error("pipeline 5: window of %d samples exceeds %d (decim=%d taps=%d)", W, 64 * kI8MaxSteps, p->D, p->T); delete p; return SDR_EINVAL; }
             fits = false;
         }
         gm.ngran = nks;                                     // k steps of 64
@@ -1825,7 +1864,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 if (cost < best_cost) { best_cost = cost; best_skew = skew; }
             }
             const int plane = base + best_skew;
-            const int lds = 2 * 4 * plane + 2 * 4 * cand * kI8PartSlots * 16;   // two tile buffers + two sets of partial sums
+            // two tile buffers + two tiles of outputs + the lowest tap digits of a 12-step window
+            const int lds = 2 * 4 * plane + 2 * cand * kI8PartSlots * 16 + (ns > 2 ? kI8MaxSteps * 1024 : 0);
             if (lds > 160 * 1024 && cand > 4) continue;
             ncb = cand;
             p->plane_bytes = plane;
@@ -1944,7 +1984,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         if (per_cu > wave_cap) per_cu = wave_cap;
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
-        if (p->mfma_i8) per_cu = 1;                           // 1024 lanes, two matrix waves per SIMD
+        if (p->mfma_i8) per_cu = 1;                           // 512 lanes with 256 registers each, one workgroup per CU
         p->stream_blocks = ncu * per_cu;
     }
 
@@ -2011,20 +2051,20 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         std::vector<long long> q(p->T);
         for (int i = 0; i < p->T; ++i) q[i] = std::llround(std::ldexp(d->taps[i], F));
         p->yscale = (float)std::ldexp(1.0, -(F + 11) + 8);     // Q11 samples; the kernel's sums start at weight 2^8
-        std::vector<int> rowsum((size_t)4 * 4 * 16, 0);        // [wave][digit][row]
-        at8.assign((size_t)4 * kI8Steps * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
-        for (int w = 0; w < 4; ++w)
-            for (int sidx = 0; sidx < kI8Steps; ++sidx)
+        std::vector<int> rowsum((size_t)4 * 16, 0);            // [digit][row]
+        at8.assign((size_t)kI8MaxSteps * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
+        {
+            for (int ks = 0; ks < kI8MaxSteps; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
                     unsigned char dg[4][16];
                     for (int c = 0; c < 16; ++c) {
-                        const long long k = 64LL * (w + 4 * sidx) + 16 * (lane >> 4) + c;
+                        const long long k = 64LL * ks + 16 * (lane >> 4) + c;
                         const long long t = (long long)p->D * (lane & 15) + p->Tback - k;
                         long long r = (t >= 0 && t < p->T) ? q[t] : 0;
                         for (int di = 0; di < 4; ++di) {
                             const long long dgt = ((r + 128) & 255) - 128;       // balanced digit in [-128, 127]
                             dg[di][c] = (unsigned char)(dgt & 255);
-                            rowsum[((size_t)w * 4 + di) * 16 + (lane & 15)] += (int)dgt;
+                            rowsum[(size_t)di * 16 + (lane & 15)] += (int)dgt;
                             r = (r - dgt) / 256;
                         }
                     }
@@ -2032,26 +2072,26 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                         uint32_t v[4];
                         for (int u = 0; u < 4; ++u)
                             v[u] = dg[di][4 * u] | ((uint32_t)dg[di][4 * u + 1] << 8) | ((uint32_t)dg[di][4 * u + 2] << 16) | ((uint32_t)dg[di][4 * u + 3] << 24);
-                        at8[(((size_t)w * kI8Steps + sidx) * 4 + di) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
+                        at8[((size_t)ks * 4 + di) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
                     }
                 }
-        // bt8[wave][lane]: lane (j, kq) holds rows 4*kq + 0..3 of every column; the digits' terms
-        // 128 * rowsum (weights 2^0..2^24, nothing at 2^32) combined like the kernel's accumulators
-        bt8.assign((size_t)4 * 64, make_uint4(0u, 0u, 0u, 0u));
-        for (int w = 0; w < 4; ++w)
-            for (int lane = 0; lane < 64; ++lane) {
-                float bf[4];
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * (lane >> 4) + r;
-                    const int *rs = &rowsum[(size_t)w * 4 * 16 + row];        // [digit * 16]
-                    // digit d meets the low bytes at weight 2^(8d); weight 0 (digit 0) is not computed
-                    const int t12 = 128 * rs[32] * 256 + 128 * rs[16], t34 = 128 * rs[48];
-                    bf[r] = std::fmaf((float)t34, 65536.0f, (float)t12);
-                }
-                uint4 u;
-                std::memcpy(&u, bf, 16);
-                bt8[(size_t)w * 64 + lane] = u;
+        }
+        // bt8[lane]: lane (j, kq) holds rows 4*kq + 0..3 of every column; digit d meets the low bytes in
+        // accumulator d-1 (weight 0, digit 0, is not computed): 128 * rowsum, combined like the
+        // kernel's accumulators
+        bt8.assign((size_t)64, make_uint4(0u, 0u, 0u, 0u));
+        for (int lane = 0; lane < 64; ++lane) {
+            float bf[4];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                const float lo = std::fmaf((float)(128 * rowsum[32 + row]), 256.0f, (float)(128 * rowsum[16 + row]));
+                const float hi = std::fmaf(0.0f, 256.0f, (float)(128 * rowsum[48 + row]));
+                bf[r] = std::fmaf(hi, 65536.0f, lo);
             }
+            uint4 u;
+            std::memcpy(&u, bf, 16);
+            bt8[lane] = u;
+        }
     }
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
     if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_atab8, at8.size() * sizeof(uint4));

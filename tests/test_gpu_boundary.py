@@ -118,16 +118,18 @@ def test_fm_loop_through_source_shim(oracle, tmp_path):
         assert dd.max() <= 1 and np.count_nonzero(dd) <= max(4, got_pcm.size // 500)
 
 
+@pytest.mark.parametrize("pipe", [0, 5])
 @pytest.mark.parametrize("mode", ["fm", "env", "iq"])
-def test_stream_blocks_equal_one_shot(sdr, oracle, mode):
+def test_stream_blocks_equal_one_shot(sdr, oracle, mode, pipe):
     """a12: pushing blocks through sdr_fir_stream gives the one-shot result on the concatenation
-    (history carried across blocks), whatever the block sizes."""
+    (history carried across blocks), whatever the block sizes -- bit for bit on the int8 matrix
+    kernel too (pipe 5), whose outputs are exact integer sums over the whole window."""
     m = {"fm": sdr.MODE_FM, "env": sdr.MODE_ENV, "iq": sdr.MODE_IQ}[mode]
     n = 700_001
     D, T = 10, 101
     iq = oracle.synth_fm_i16(n, fs=2.0e6, ftone=1700.0, dev=25000.0)
     h = oracle.create_fir_filter(T, 0.09, "hann")
-    plan = sdr.FirPlan(h, D, mode=m)
+    plan = sdr.FirPlan(h, D, mode=m, pipeline=pipe)
     whole = plan.execute_host(iq)
     stream = sdr.FirStream(plan, 131072)
     rng = np.random.default_rng(7)
@@ -149,10 +151,8 @@ def test_stream_blocks_equal_one_shot(sdr, oracle, mode):
         assert np.abs(got - whole).max() <= 1e-6
     else:
         assert np.abs(got - whole).max() <= 2e-6
-    if plan.info()["kernel"] != "mfma_i8":
-        # the vector-unit kernels give every output one summation order whatever the tiling; the
-        # int8 matrix kernel rounds once per tile position, so a block boundary may move an ulp
-        assert (got == whole).mean() > 0.99
+    # every kernel gives an output one summation order whatever the tiling
+    assert np.array_equal(got, whole)
     # the reference's per-block restart differs from this at every block start (the transient)
     with pytest.raises(sdr.SdrError):
         stream.push(iq[: 2 * 10]); stream.push(iq[: 2 * 10]); stream.push(iq[: 2 * 10])

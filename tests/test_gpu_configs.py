@@ -112,8 +112,9 @@ def test_cfg4_full_size(sdr, oracle):
 def test_two_ranks_time_split_through_hip(sdr, oracle, pipe):
     """shard.plan_time_shards with the HIP kernels as the per-rank compute: two 'ranks' run back to
     back on this GPU, each holding only its own resident window, and their concatenation must equal
-    the one-piece launch -- bit for bit for the vector-unit kernel, to one float32 ulp for the int8
-    matrix kernel (its outputs are rounded once per tile position)."""
+    the one-piece launch bit for bit -- for the vector-unit kernel (one summation order per output) and
+    for the int8 matrix kernel (an output is one exact integer sum over its whole window, whatever
+    tile or shard it falls into)."""
     from sdr_amd import shard
     n_total, D, T = 3_000_017, 10, (64 if pipe == 1 else 511)
     h = sdr.create_fir_filter(T, 0.8 / D, "hann")
@@ -137,10 +138,7 @@ def test_two_ranks_time_split_through_hip(sdr, oracle, pipe):
             parts.append(d_out.to_numpy(np.float32, sh.n_out))
         got = np.concatenate(parts)
         assert got.shape == one.shape
-        if pipe == 1:
-            assert np.array_equal(got, one)
-        else:
-            assert np.abs(got.astype(np.float64) - one).max() <= 2e-6
+        assert np.array_equal(got, one)
         # and the one-piece result is the oracle's
         want = oracle.chain_i16(iq, D, h, oracle.MODE_FM if mode == sdr.MODE_FM else oracle.MODE_ENV)
         assert np.abs(one.astype(np.float64)[T:] - want[T:]).max() <= 1e-5 * (0.5 if mode == sdr.MODE_FM else 1.0)

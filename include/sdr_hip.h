@@ -68,7 +68,9 @@ enum sdr_status {
  *                      small, so rule (1) usually applies to them; nothing else is special about them.
  *                      Where y[m] is EXACTLY zero the reference's 0 / +-pi (from the signs of its zeros,
  *                      bladerf_apt_demod.cpp:419-421) is reproduced bit for bit by every kernel;
- *                  (3) pipeline 5 only: taps below 2^-31 of the largest tap vanish in its fixed point.
+ *                  (3) pipeline 5 only (the int8 matrix kernel, which the automatic choice takes for most
+ *                      int16 shapes; pin pipeline 1 or 2 to rule it out): taps below 2^-31 of the largest
+ *                      tap vanish in its fixed point.
  *                      After a run of >= T zero samples in mid-stream, the first output whose window
  *                      meets a non-zero sample ONLY through such taps has y == 0 here and a tiny y in
  *                      the reference: that output and its predecessor report the angle of a zero vector
@@ -175,8 +177,11 @@ typedef struct sdr_fir_desc {
                              5 = Toeplitz GEMM on the int8 matrix pipe: samples as their two
                              bytes, taps as four base-256 digits, exact int32 accumulation
                              (windows T + 15*D up to 768 samples; at least 2 taps; int16 without
-                             mixer only; leave outputs_per_lane and threads 0).  Chosen automatically where a
-                             measured cost model (tiles vs taps per sample) puts it ahead.  Taps
+                             mixer only; leave outputs_per_lane and threads 0; 512 lanes).  An output is
+                             one exact integer sum over its window: its bits do not depend on tiling,
+                             block hand-off or sharding.  Chosen automatically where a measured cost model
+                             (tiles vs taps per sample) puts it ahead -- everywhere but small decimation
+                             factors with few taps.  Taps
                              smaller than 2^-31 of the largest one are dropped by the fixed point;
                              the discriminator outputs of a stream's start-up transient, where
                              such taps can decide the angle, are recomputed with float32 taps.

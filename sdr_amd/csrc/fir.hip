@@ -1290,7 +1290,8 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
 
 // NS = k steps of the window, rounded up to a multiple of four (steps past the window carry zero taps
 // and are skipped; the staged tile covers NS steps, so no sample read leaves it).
-template <int NS, int NCB>
+// PRE = octets (8 samples) per helper lane and tile: 256 * PRE * 8 samples cover the staged tile.
+template <int NS, int NCB, int PRE>
 __global__ void __launch_bounds__(512, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
@@ -1428,7 +1429,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         }
         // raw samples of two tiles travel at any time: set p&1 holds tile p until it is staged in
         // phase p and is then refilled with tile p+2
-        constexpr int kI8Pre = NCB > 4 ? 6 : 4;                // octets per lane and tile held in registers
+        constexpr int kI8Pre = PRE;                            // octets per lane and tile held in registers
         uint4 w0[kI8Pre][2], w1[kI8Pre][2];
         auto request = [&](int n, uint4 (&w)[kI8Pre][2]) {     // n-th tile of this workgroup
             // unconditional (past the end: the last tile again, unused): a skipped request would make
@@ -1470,10 +1471,6 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 #pragma unroll
                     for (int k = 0; k < kI8Pre; ++k)
                         if (256 * k + st < n_oct) put(256 * k + st, w[k][0], w[k][1]);
-                }
-                for (int oct = 256 * kI8Pre + st; oct < n_oct; oct += 256) {   // very wide tiles only
-                    uint4 q0 = i8_fetch(tl, 2 * oct), q1 = i8_fetch(tl, 2 * oct + 1);
-                    put(oct, i8_repair(tl, 2 * oct, q0), i8_repair(tl, 2 * oct + 1, q1));
                 }
             }
             clk.mark(0);
@@ -1601,19 +1598,24 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
     *what = "fir kernel launch";
     if (p->mfma_i8) {
         const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
-#define SDR_I8(NS, CB)                                                                           \
+#define SDR_I8P(NS, CB, PRE)                                                                     \
     do {                                                                                         \
-        SDR_OPT_IN(fir_mfma_i8_kernel<NS, CB>);                                                  \
-        fir_mfma_i8_kernel<NS, CB><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
+        SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE>));                                           \
+        fir_mfma_i8_kernel<NS, CB, PRE><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale,                 \
                                                                   g.store_from > g.out_begin ? p->d_ftaps : nullptr); \
     } while (0)
+        // the helper lanes hold a whole staged tile in registers: 4, 6 or 8 octets each (plan creation
+        // refuses tiles beyond 256 * 8 octets)
+        const int pre = ((p->s_gran + 1) / 2 + 255) / 256;
+#define SDR_I8(NS, CB) do { if (pre <= 4) SDR_I8P(NS, CB, 4); else if (pre <= 6) SDR_I8P(NS, CB, 6); else SDR_I8P(NS, CB, 8); } while (0)
         const int ns = (p->ngran + 3) / 4;
         if (p->R == 4) { if (ns <= 1) SDR_I8(4, 8); else if (ns == 2) SDR_I8(8, 8); else SDR_I8(12, 8); }
         else if (ns <= 1) SDR_I8(4, 4);
         else if (ns == 2) SDR_I8(8, 4);
         else SDR_I8(12, 4);
 #undef SDR_I8
+#undef SDR_I8P
         return hipGetLastError();
     }
     if (p->ksplit) {
@@ -1797,23 +1799,27 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         p->mfma = true;
     }
     // Automatic choice between the vector-unit kernels and the int8 matrix kernel, from a sweep of
-    // ten shapes on MI355X (T = 64..511, D = 4..20), in ms per 2^28 samples:
+    // fifteen shapes on MI355X (T = 64..700, D = 4..25), in ms per 2^28 samples:
     //   vector unit:  max(0.256 [HBM], 0.17 + 0.0125 * T/D)
-    //   matrix pipe:  max(0.26 [HBM], tiles per CU * time per tile); a tile is 1024 outputs (1.85 | 2.1 |
-    //                 3.2 us for 1 | 2 | 3 k steps per matrix wave) when the LDS holds it, else 512
-    //                 (1.2 | 1.35 | 1.7 us)
-    // The matrix kernel's time follows the number of tiles, not the filter length.
+    //   matrix pipe:  max(HBM at 5.4 TB/s, tiles per CU * time per tile); a tile of 1024 outputs takes
+    //                 0.7 + 0.112 * (k steps of the window) + 0.085 * D microseconds (matrix waves: MFMAs
+    //                 per step; helper waves: samples per tile), a tile of 512 outputs (when the LDS or
+    //                 the helper lanes' registers do not hold the larger one) 0.55 of that
+    // The matrix kernel's time follows the number of tiles, not the filter length; it loses where
+    // tiles are many and windows short (D <= 4 with few taps).
     bool auto_i8 = false;
-    if (d->pipeline == 0 && raw_possible && !d->outputs_per_lane && !d->threads) {
+    if (d->pipeline == 0 && raw_possible && !d->outputs_per_lane && !d->threads && d->n_taps >= 2) {
         const double t_valu = std::fmax(0.256, 0.17 + 0.0125 * (double)d->n_taps / (double)d->decim);
         const int Wn = roundup(d->n_taps - 1, 4) + 15 * d->decim + 1;
-        const int steps = ((Wn + 63) / 64 + 3) / 4;
-        const bool big = 2 * 4 * (roundup(16 * d->decim * 63 + 256 * steps, 256) + 240) + 2 * 8 * kI8PartSlots * 16 + (steps > 2 ? 12 * 1024 : 0) <= 160 * 1024;
-        const double per_tile_us = big ? (steps <= 1 ? 1.85 : (steps == 2 ? 2.1 : 3.2))
-                                       : (steps <= 1 ? 1.2 : (steps == 2 ? 1.35 : 1.7));
+        const int nks = (Wn + 63) / 64, steps = (nks + 3) / 4;
+        const long long s_big = 16LL * d->decim * 63 + 256LL * steps;
+        const bool big = s_big <= 8 * 256 * 8 &&
+                         2 * 4 * (roundup((int)s_big, 256) + 240) + 2 * 8 * kI8PartSlots * 16 + (steps > 2 ? 12 * 1024 : 0) <= 160 * 1024;
+        const double tile_us = (0.7 + 0.112 * nks + 0.085 * d->decim) * (big ? 1.0 : 0.55);
         const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
-        const double t_i8 = std::fmax(0.26, tiles_per_cu * per_tile_us * 1e-3);
-        auto_i8 = t_i8 < 0.9 * t_valu;
+        const double t_hbm = (4.0 + 4.0 / d->decim) * 268435456.0 / 5.4e12 * 1e3;
+        const double t_i8 = std::fmax(t_hbm, tiles_per_cu * tile_us * 1e-3);
+        auto_i8 = t_i8 < t_valu;
     }
     if (d->pipeline == 5 && d->n_taps < 2) {
         // no history halo: a tile at the stream's end could hold fewer than the four valid samples its
@@ -1866,10 +1872,12 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             const int plane = base + best_skew;
             // two tile buffers + two tiles of outputs + the lowest tap digits of a 12-step window
             const int lds = 2 * 4 * plane + 2 * cand * kI8PartSlots * 16 + (ns > 2 ? kI8MaxSteps * 1024 : 0);
-            if (lds > 160 * 1024 && cand > 4) continue;
+            // the helper lanes hold the staged tile in registers, at most 8 octets of samples each
+            const bool wide = (s_tile / 4 + 1) / 2 > 256 * 8;
+            if ((lds > 160 * 1024 || wide) && cand > 4) continue;
             ncb = cand;
             p->plane_bytes = plane;
-            gm.lds_bytes = lds;
+            gm.lds_bytes = wide ? 161 * 1024 : lds;         // (reported as "does not fit" below)
             gm.s_gran = (int)(s_tile / 4);                  // quads of samples staged
         }
         gm.a_gran = gm.s_gran;
@@ -2140,7 +2148,7 @@ extern "C" int sdr_fir_plan_info(const sdr_fir_plan *p, int *R, int *NT, int *ld
 {
     if (!p) return SDR_EINVAL;
     if (R) *R = p->R;
-    if (NT) *NT = p->NT;
+    if (NT) *NT = p->mfma_i8 ? 512 : p->NT;       // (pipeline 5: NT is its 256 finishing lanes; the workgroup has 512)
     if (lds) *lds = p->lds_bytes;
     return SDR_OK;
 }

@@ -652,8 +652,10 @@ def test_long_filter_automatic_choice_and_tiny_streams(sdr, oracle):
     h = oracle.create_fir_filter(201, 0.3, "hann")
     p = sdr.FirPlan(h, 3, mode=sdr.MODE_IQ)
     assert p.info()["kernel"] == "mfma_i8"
-    for T, D, want_i8 in ((64, 10, False), (101, 5, True), (101, 20, False), (128, 8, True), (200, 10, True),
-                          (195, 15, True), (511, 10, True), (511, 15, True)):
+    # (the matrix kernel loses where tiles are many and windows short: small decimation factors, few taps)
+    for T, D, want_i8 in ((64, 10, True), (101, 5, True), (101, 20, True), (128, 8, True), (200, 10, True),
+                          (195, 15, True), (511, 10, True), (511, 15, True), (64, 4, True), (300, 25, True),
+                          (16, 2, False), (32, 4, False), (9, 1, False)):
         k = sdr.FirPlan(oracle.create_fir_filter(T, 0.5 / D, "hann"), D, mode=sdr.MODE_FM).info()["kernel"]
         assert (k == "mfma_i8") == want_i8, (T, D, k)
     rng = np.random.default_rng(5)

@@ -1148,6 +1148,12 @@ __device__ __forceinline__ int i8_tile_index(int n)
     return n * G + slot;
 }
 
+// channel of tile t (one scalar compare instead of a division when the launch has a single channel)
+__device__ __forceinline__ int i8_tile_channel(const FirGeom &g, int t)
+{
+    return g.total_tiles == g.tiles_per_ch ? 0 : t / g.tiles_per_ch;
+}
+
 struct I8Tile {
     const unsigned char *vbase;   // the tile's first valid sample (inside the caller's buffer; wave-uniform)
     int lo, hi;                   // valid samples of the tile, tile-relative: [lo, hi)
@@ -1166,7 +1172,7 @@ __device__ __forceinline__ int i8_clamp_diff(long long d, int n)
 
 __device__ __forceinline__ I8Tile i8_tile(const FirGeom &g, const uint32_t *__restrict__ in, int t)
 {
-    const int ch = t / g.tiles_per_ch;
+    const int ch = i8_tile_channel(g, t);
     const long long W0 = (g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile) * g.D - g.Tback;
     const int n = 4 * g.s_gran;
     const int lo = i8_clamp_diff(g.lo_valid - W0, n);
@@ -1271,7 +1277,7 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
     const float *pa = ybuf + par * NCB * (4 * kI8PartSlots) + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
     const float *pb = ybuf + par * NCB * (4 * kI8PartSlots) + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
     const int t = i8_tile_index(n);
-    const int ch = t / g.tiles_per_ch;
+    const int ch = i8_tile_channel(g, t);
     const long long M0 = g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile;
     float2 y[RH], ynext;
     if constexpr (RH == 4) {
@@ -1431,23 +1437,22 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // phase p and is then refilled with tile p+2
         constexpr int kI8Pre = PRE;                            // octets per lane and tile held in registers
         uint4 w0[kI8Pre][2], w1[kI8Pre][2];
-        auto request = [&](int n, uint4 (&w)[kI8Pre][2]) {     // n-th tile of this workgroup
-            // unconditional (past the end: the last tile again, unused): a skipped request would make
-            // the registers conditionally defined and hipcc would copy them right after the loads
-            n = n < n_t ? n : n_t - 1;
-            const I8Tile tl = i8_tile(g, in, i8_tile_index(n));
+        // n-th tile of this workgroup, and its descriptor kept (in scalar registers) until it is staged.
+        // Unconditional (past the end: the last tile again, unused): a skipped request would make the
+        // registers conditionally defined and hipcc would copy them right after the loads
+        auto request = [&](int n, uint4 (&w)[kI8Pre][2], I8Tile &tl) {
+            tl = i8_tile(g, in, i8_tile_index(n < n_t ? n : n_t - 1));
 #pragma unroll
             for (int k = 0; k < kI8Pre; ++k)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) w[k][h] = i8_fetch(tl, 2 * (256 * k + st) + h);
         };
-        auto phase = [&](int p, uint4 (&w)[kI8Pre][2]) {
+        auto phase = [&](int p, uint4 (&w)[kI8Pre][2], I8Tile &tl) {
             // (past the last tile: the last one again, into a buffer nobody reads any more -- a skipped
             // staging would leave the set's loads pending on one path into the request below, and hipcc
             // would then wait for every outstanding load, the other set's included, on all paths)
             if (!(SDR_I8_ABL & 2)) {
                 unsigned char *buf = smem + (p & 1) * buf_bytes;
-                const I8Tile tl = i8_tile(g, in, i8_tile_index(p < n_t ? p : n_t - 1));
                 auto put = [&](int oct, uint4 q0, uint4 q1) {
                     uint32_t il[2], ih[2], ql[2], qh[2];
                     i8_split4(q0, il[0], ih[0], ql[0], qh[0]);
@@ -1474,18 +1479,19 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 }
             }
             clk.mark(0);
-            request(p + 2, w);
+            request(p + 2, w, tl);
             clk.mark(1);
             clk.arrive();
             lds_only_barrier();
             clk.leave();
         };
-        request(0, w0);
-        request(1, w1);
+        I8Tile tl0, tl1;
+        request(0, w0, tl0);
+        request(1, w1, tl1);
         clk.start();
         for (int p = 0; p < n_ph; p += 2) {
-            phase(p, w0);
-            phase(p + 1, w1);
+            phase(p, w0, tl0);
+            phase(p + 1, w1, tl1);
         }
     }
     clk.flush(outv, g.out_end - g.out_begin, n_ph);

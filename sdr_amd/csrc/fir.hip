@@ -1614,11 +1614,13 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         // the helper lanes hold a whole staged tile in registers: 4, 6 or 8 octets each (plan creation
         // refuses tiles beyond 256 * 8 octets)
         const int pre = ((p->s_gran + 1) / 2 + 255) / 256;
-#define SDR_I8(NS, CB) do { if (pre <= 4) SDR_I8P(NS, CB, 4); else if (pre <= 6) SDR_I8P(NS, CB, 6); else SDR_I8P(NS, CB, 8); } while (0)
+#define SDR_I8(NS, CB) do { if (pre <= 4 && CB == 8) SDR_I8P(NS, 8, 4); else if (pre <= 6) SDR_I8P(NS, CB, 6); else SDR_I8P(NS, CB, 8); } while (0)
+        // 512-output tiles are taken for D >= 16 only (the larger tile then exceeds the LDS or the helper
+        // lanes' registers): their windows have more than four steps and their tiles more than four
+        // octets per lane, so those instantiations do not exist (a wider one would do the same work)
         const int ns = (p->ngran + 3) / 4;
         if (p->R == 4) { if (ns <= 1) SDR_I8(4, 8); else if (ns == 2) SDR_I8(8, 8); else SDR_I8(12, 8); }
-        else if (ns <= 1) SDR_I8(4, 4);
-        else if (ns == 2) SDR_I8(8, 4);
+        else if (ns <= 2) SDR_I8(8, 4);
         else SDR_I8(12, 4);
 #undef SDR_I8
 #undef SDR_I8P

@@ -667,6 +667,28 @@ def test_long_filter_automatic_choice_and_tiny_streams(sdr, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,D", [(64, 4), (24, 15), (128, 8), (255, 4), (200, 10), (195, 15), (600, 4), (511, 10),
+                                 (511, 15), (101, 20), (128, 16), (300, 25), (60, 31), (300, 20), (100, 25)])
+def test_int8_matrix_kernel_instantiations(sdr, oracle, T, D):
+    """every instantiation of the int8 matrix kernel (window of 4 / 8 / 12 k steps x tile of 1024 / 512
+    outputs x 4 / 6 / 8 octets per helper lane) against the oracle, all modes, on a stream with ragged
+    ends and full-range samples"""
+    rng = np.random.default_rng(T * 100 + D)
+    n = 4 * 1024 * D + 3 * D + 7 + T                       # a few tiles per workgroup slot, ragged end
+    iq = oracle.synth_fm_i16(n, fs=1.0e6, ftone=700.0, dev=40000.0, amp=20000.0)
+    iq = np.clip(iq.astype(np.int32) + rng.integers(-3000, 3001, iq.size), -32768, 32767).astype(np.int16)
+    h = oracle.create_fir_filter(T, 0.8 / D, "hann")
+    x = oracle.unpack_scale_i16(iq)
+    y = oracle.fir_decimate(x, D, h)
+    for mode, want in ((sdr.MODE_IQ, y), (sdr.MODE_ENV, np.abs(y))):
+        plan = sdr.FirPlan(h, D, mode=mode, pipeline=5)
+        assert plan.info()["kernel"] == "mfma_i8"
+        check_linear(plan.execute_host(iq), want, f"i8 {T}/{D} mode {mode}")
+    fm = oracle.polar_discriminator(y, 1 / TWO_PI)
+    check_fm(sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5).execute_host(iq), fm, y, 1 / TWO_PI, f"i8 {T}/{D} fm")
+
+
+@pytest.mark.gpu
 def test_int8_matrix_kernel_shards_and_channels(sdr, oracle):
     """the int8 matrix kernel behind the other entry points: time shards with their history halo
     (tiles that start before / end after the resident window), channel-major batches (tiles of

@@ -1424,15 +1424,6 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         const int st = tid - 256;                              // 0..255
         const int cI = g.swap_iq ? 1 : 0;                      // Q-first input swaps the component planes
         const int n_oct = (g.s_gran + 1) / 2;                  // octets per tile
-        if (ftaps) {
-            // outputs [out_begin, store_from) of every channel: see i8_startup_fm_output; dealt over the
-            // helper waves of the whole grid, done before the first tile is finished
-            const long long n_su = g.store_from - g.out_begin, total = n_su * (g.total_tiles / g.tiles_per_ch);
-            for (long long idx = 4LL * blockIdx.x + (st >> 6); idx < total; idx += 4LL * gridDim.x) {
-                const long long ch = idx / n_su;
-                i8_startup_fm_output(in, (float *)outv, ftaps, g, g.out_begin + (idx - ch * n_su), ch, st & 63);
-            }
-        }
         // raw samples of two tiles travel at any time: set p&1 holds tile p until it is staged in
         // phase p and is then refilled with tile p+2
         constexpr int kI8Pre = PRE;                            // octets per lane and tile held in registers
@@ -1488,6 +1479,15 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         I8Tile tl0, tl1;
         request(0, w0, tl0);
         request(1, w1, tl1);
+        if (ftaps) {
+            // outputs [out_begin, store_from) of every channel: see i8_startup_fm_output; dealt over the
+            // helper waves of the whole grid, done behind the first two requests (their loads are in flight meanwhile)
+            const long long n_su = g.store_from - g.out_begin, total = n_su * (g.total_tiles / g.tiles_per_ch);
+            for (long long idx = 4LL * blockIdx.x + (st >> 6); idx < total; idx += 4LL * gridDim.x) {
+                const long long ch = idx / n_su;
+                i8_startup_fm_output(in, (float *)outv, ftaps, g, g.out_begin + (idx - ch * n_su), ch, st & 63);
+            }
+        }
         clk.start();
         for (int p = 0; p < n_ph; p += 2) {
             phase(p, w0, tl0);

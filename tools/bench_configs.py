@@ -23,9 +23,16 @@ PEAK = 8000.0
 
 
 def timed(fn, iters):
-    """kernel ms per launch: warm the clocks up first (the first ~20 launches after idle run
-    10-15 % slow), then the best of three event-timed runs of `iters` launches"""
-    fn(40)
+    """kernel ms per launch: warm the clocks up first, as bench.py does -- batches of launches until two
+    consecutive ones agree within 1 % (at most 2 s; a fresh process ramps for ~60 ms of load, which is
+    hundreds of launches of a 70 us kernel) -- then the best of three event-timed runs of `iters`"""
+    import time
+    t0, prev = time.perf_counter(), None
+    while time.perf_counter() - t0 < 2.0:
+        cur = fn(max(20, iters))
+        if prev is not None and abs(cur - prev) <= 0.01 * prev and time.perf_counter() - t0 > 0.1:
+            break
+        prev = cur
     return min(fn(iters) for _ in range(3))
 
 
@@ -162,4 +169,4 @@ if __name__ == "__main__":
     sdr_amd.init(0)
     which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5", "handoff"]
     for w in which:
-        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5, "handoff": handoff}[w](10)
+        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5, "handoff": handoff}[w](20)

@@ -13,7 +13,8 @@ n = 1 << 24
 d_in = sdr_amd.DevBuf(n * 4 + 64)
 sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=624e3, ftone=2400.0, dev=17000.0, amp=1800.0, noise_lsb=8, seed=2)
 bad = 0
-for (T, D, mode) in ((511, 10, sdr_amd.MODE_FM), (511, 15, sdr_amd.MODE_ENV), (200, 10, sdr_amd.MODE_IQ), (101, 5, sdr_amd.MODE_FM)):
+for (T, D, mode) in ((511, 10, sdr_amd.MODE_FM), (511, 15, sdr_amd.MODE_ENV), (200, 10, sdr_amd.MODE_IQ), (101, 5, sdr_amd.MODE_FM),
+                     (64, 10, sdr_amd.MODE_FM), (101, 20, sdr_amd.MODE_FM), (300, 25, sdr_amd.MODE_ENV), (60, 31, sdr_amd.MODE_IQ)):
     h = sdr_amd.create_fir_filter(T, 0.8 / D, "hann")
     p = sdr_amd.FirPlan(h, D, mode=mode, pipeline=5)
     cnt = p.out_count(n)

@@ -1,7 +1,7 @@
 """CPU model of the arithmetic behind FIR plan pipeline 5 (fir_mfma_i8_kernel, sdr_amd/csrc/fir.hip):
 int16 samples as two signed bytes, taps as four balanced base-256 digits of a 31-bit fixed-point
 value, seven of the eight byte products (the weight-2^0 one is below 2^-30 of full scale and left out)
-in four exact integer accumulators per output, one float32 combination.  The kernel itself is
+in four exact integer accumulators per output over the whole window, one float32 combination.  The kernel itself is
 checked on the GPU (tests/test_gpu_parity.py); this file pins the scheme's claims -- digit ranges,
 accumulator bounds, exact zeros under zero pre-history, accuracy against the float64 oracle --
 with numpy integers, no GPU."""
@@ -45,16 +45,18 @@ def model_output(x_i, q_digits, F, m, D):
         if d > 0:
             acc[d] += int((q_digits[d] * lo).sum())      # weight 2^(8d); the kernel leaves weight 2^0 out
         acc[d + 1] += int((q_digits[d] * hi).sum())      # weight 2^(8(d+1))
-    assert np.abs(acc).max() < 2 ** 31
+    assert np.abs(acc).max() < 2 ** 24                   # exact in int32 and in the float32 conversion
     bias = np.array([0] + [128 * int(q_digits[d].sum()) for d in range(1, 4)] + [0], np.int64)
     dropped = int((q_digits[0] * (lo + 128)).sum())      # what the missing product would have added
     f = np.float32
 
-    def combine(a):                                      # the kernel's float32 sequence (weights 2^8 .. 2^32)
-        t12 = np.int64(a[2]) * 256 + a[1]
-        t34 = np.int64(a[4]) * 256 + a[3]
-        assert abs(int(t12)) < 2 ** 31 and abs(int(t34)) < 2 ** 31
-        return f(np.float64(f(t34)) * 65536.0 + np.float64(f(t12)))      # fma: one rounding
+    def fma(a, b, c):                                    # float32 fused multiply-add: one rounding
+        return f(np.float64(a) * np.float64(b) + np.float64(c))
+
+    def combine(a):                                      # the kernel's float32 sequence (weights 2^8 .. 2^32):
+        lo_ = fma(f(a[2]), f(256.0), f(a[1]))            # every accumulator is converted on its own (|acc| < 2^24
+        hi_ = fma(f(a[4]), f(256.0), f(a[3]))            # over a 768-sample window: exact), two fma by 256, one by 65536
+        return fma(hi_, f(65536.0), lo_)
     exact = sum(int(acc[w] + bias[w]) << (8 * w) for w in range(5)) + dropped
     y32 = f(f(combine(acc) + combine(bias)) * f(np.ldexp(1.0, -(F + 11) + 8)))
     assert abs(dropped) <= 128 * 255 * q_digits.shape[1]                 # < 2^-30 of the 2^45 full-scale sum per tap

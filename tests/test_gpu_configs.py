@@ -1,4 +1,4 @@
-"""GPU tests at the sizes BASELINE.json names (configs[2] channelizer, configs[3] waterfall) and of
+"""GPU tests at the sizes BASELINE.json names (configs[2] channelizer, configs[3] waterfall, configs[4] APT chain) and of
 the multi-rank splits with the HIP kernels doing the per-rank compute (tests/test_shard_gloo.py
 covers the collectives with the CPU oracle standing in for the kernels).
 
@@ -106,6 +106,55 @@ def test_cfg4_full_size(sdr, oracle):
         row = d_out.to_numpy(np.float32, nfft, f * nfft * 4).astype(np.float64)
         p_freq = float((10.0 ** (row / 10.0)).sum())
         assert abs(p_freq - p_time) <= 1e-4 * p_time, (f, p_freq, p_time)
+
+
+def test_cfg5_full_size(sdr, oracle):
+    """BASELINE configs[4]: the APT chain at 2^26 samples -- 511 taps / 10 + discriminator (int8 matrix
+    kernel), +2400/62400 mixer folded into 511 complex taps / 15, envelope (K-split kernel, chosen from
+    the size hint).  Oracle on the head of the stream (zero pre-history) and on its tail (a slice with
+    its own history: a constant offset of the mixer's phase does not change an envelope); sentinels
+    behind both outputs."""
+    n, D1, D2, T = 1 << 26, 10, 15, 511
+    fr = 2400 / 62400.0
+    h1 = sdr.create_fir_filter(T, 20800 / 62400.0 / 5, "hann")
+    h2 = sdr.create_fir_filter(T, fr, "hann")
+    p1 = sdr.FirPlan(h1, D1, mode=sdr.MODE_FM)
+    n6 = p1.out_count(n)
+    p2 = sdr.FirPlan(h2, D2, mode=sdr.MODE_ENV, input=sdr.IN_F32_REAL, mix_fr=fr, size_hint=n6)
+    n9 = p2.out_count(n6)
+    assert p1.info()["kernel"] == "mfma_i8" and p2.info()["kernel"] == "ksplit"
+    d_in = sdr.DevBuf(n * 4)
+    sdr.capi.synth_fm_i16_dev(d_in, n, fs=624e3, ftone=2400.0, dev=17000.0, amp=1800.0, noise_lsb=4, seed=5)
+    SENT = np.float32(-777.5)
+    d_x6, d_x9 = sdr.DevBuf((n6 + 8) * 4), sdr.DevBuf((n9 + 8) * 4)
+    fill(sdr, d_x6, SENT, 8, offset_bytes=n6 * 4)
+    fill(sdr, d_x9, SENT, 8, offset_bytes=n9 * 4)
+    assert p1.execute_dev(d_in, n, d_x6, n6) == n6
+    assert p2.execute_dev(d_x6, n6, d_x9, n9) == n9
+    sdr.sync()
+    assert (d_x6.to_numpy(np.float32, 8, n6 * 4) == SENT).all() and (d_x9.to_numpy(np.float32, 8, n9 * 4) == SENT).all()
+    # head: the oracle's chain on the first 2^19 samples
+    m = 1 << 19
+    w9, w6 = oracle.apt_chain_i16(d_in.to_numpy(np.int16, 2 * m), D1, h1, fr, D2, h2)
+    g6 = d_x6.to_numpy(np.float32, w6.size).astype(np.float64)
+    g9 = d_x9.to_numpy(np.float32, w9.size).astype(np.float64)
+    s6 = T // D1 + 2                                    # the start-up transient: ill-conditioned angles (sdr_hip.h)
+    s9 = s6 // D2 + 2 + T // D2
+    assert np.abs(g6 - w6)[s6:].max() <= 5e-6
+    assert np.abs(g9 - w9)[s9:-(T // D2) - 2].max() <= 5e-6
+    # tail: the slice from sample s0 (a multiple of D1*D2, so both decimators stay in phase) to the end
+    s0 = (n - 450_000) // (D1 * D2) * (D1 * D2)
+    L = n - s0
+    w9t, w6t = oracle.apt_chain_i16(d_in.to_numpy(np.int16, 2 * L, s0 * 4), D1, h1, fr, D2, h2)
+    o6, o9 = s0 // D1, s0 // (D1 * D2)
+    g6t = d_x6.to_numpy(np.float32, n6 - o6, o6 * 4).astype(np.float64)
+    g9t = d_x9.to_numpy(np.float32, n9 - o9, o9 * 4).astype(np.float64)
+    k6 = min(g6t.size, w6t.size)
+    k9 = min(g9t.size, w9t.size)
+    assert k6 >= L // D1 - 2 and k9 >= L // (D1 * D2) - 2
+    assert np.abs(g6t[:k6] - w6t[:k6])[s6:].max() <= 5e-6            # past the slice's own start-up transient
+    assert np.abs(g9t[:k9] - w9t[:k9])[s9:].max() <= 5e-6
+    assert np.isfinite(d_x9.to_numpy(np.float32, n9)).all()
 
 
 @pytest.mark.parametrize("pipe", [1, 5])

@@ -196,7 +196,9 @@ typedef struct sdr_fir_desc {
     long long size_hint;  /* 0 = unknown; else the input samples a launch will typically see.  Geometry is
                              chosen for long streams by default; with a hint that says "short" (fewer lane
                              windows than two waves per SIMD) real-input plans take the K-split kernel
-                             (pipeline 6).  The choice is made once, at plan creation: a plan's outputs do
+                             (pipeline 6), and int16 plans stay on the vector-unit tile kernels where the
+                             persistent matrix kernel's ~13 us launch latency would outweigh its rate
+                             (blocks below ~2^26 samples at 64 taps / 10, ~2^22 at 511 / 10).  The choice is made once, at plan creation: a plan's outputs do
                              not depend on how a stream is cut into launches. */
 } sdr_fir_desc;
 

@@ -85,14 +85,14 @@ private:
 inline std::vector<float> fm_demod_i16(const std::vector<std::complex<int16_t>>& iq, int D,
                                        const std::vector<double>& h, double scale)
 {
-    FirPlan plan(h, D, SDR_MODE_FM, SDR_IN_I16_IQ, scale);
+    FirPlan plan(h, D, SDR_MODE_FM, SDR_IN_I16_IQ, scale, 0.0, SDR_COUNT_FLOOR, (long long)iq.size());   // the block's size: kernel choice
     return plan.run<std::complex<int16_t>, float>(iq.data(), iq.size());
 }
 // bladerf_am_demod.cpp:291-311 / bladerf_apt_demod.cpp:747-754: FIR/D -> |.|
 inline std::vector<float> envelope_i16(const std::vector<std::complex<int16_t>>& iq, int D,
                                        const std::vector<double>& h)
 {
-    FirPlan plan(h, D, SDR_MODE_ENV, SDR_IN_I16_IQ);
+    FirPlan plan(h, D, SDR_MODE_ENV, SDR_IN_I16_IQ, 1.0, 0.0, SDR_COUNT_FLOOR, (long long)iq.size());
     return plan.run<std::complex<int16_t>, float>(iq.data(), iq.size());
 }
 // bladerf_apt_demod.cpp:744-754: frequency_shift -> polyphase_decimate -> abs on a real stream
@@ -118,7 +118,7 @@ inline std::vector<float> af_fir_pick_discriminate_i16(const std::vector<std::co
                                                        const std::vector<float>& lpf, int dec_rate, double phasor_scale)
 {
     FirPlan plan(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_FM, SDR_IN_I16_IQ, phasor_scale, 0.0,
-                 SDR_COUNT_AF_SEQ);
+                 SDR_COUNT_AF_SEQ, (long long)iq.size());
     return plan.run<std::complex<int16_t>, float>(iq.data(), iq.size());
 }
 // bladerf_am_demod.cpp:294-311: af::fir, x3(dec_seq), af::abs

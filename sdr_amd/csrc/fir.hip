@@ -1828,6 +1828,13 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const double t_hbm = (4.0 + 4.0 / d->decim) * 268435456.0 / 5.4e12 * 1e3;
         const double t_i8 = std::fmax(t_hbm, tiles_per_cu * tile_us * 1e-3);
         auto_i8 = t_i8 < t_valu;
+        if (d->size_hint > 0) {
+            // a launch of the persistent matrix kernel costs ~13 us before its first output (tap digits
+            // into registers, three pipeline stages), one of the tile kernels ~4 us: short launches
+            // (below 2^26 samples at the headline shape, 2^22 at 511 / 10) stay on the vector unit
+            const double f = (double)d->size_hint / 268435456.0;
+            auto_i8 = 0.013 + t_i8 * f < 0.004 + t_valu * f;
+        }
     }
     if (d->pipeline == 5 && d->n_taps < 2) {
         // no history halo: a tile at the stream's end could hold fewer than the four valid samples its

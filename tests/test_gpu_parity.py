@@ -658,6 +658,12 @@ def test_long_filter_automatic_choice_and_tiny_streams(sdr, oracle):
                           (16, 2, False), (32, 4, False), (9, 1, False)):
         k = sdr.FirPlan(oracle.create_fir_filter(T, 0.5 / D, "hann"), D, mode=sdr.MODE_FM).info()["kernel"]
         assert (k == "mfma_i8") == want_i8, (T, D, k)
+    # a size hint that says "short launches" keeps the plan off the persistent kernel (its launch latency)
+    h64, h511 = oracle.create_fir_filter(64, 0.05, "hann"), oracle.create_fir_filter(511, 0.05, "hann")
+    for hh, hint, want_i8 in ((h64, 131072, False), (h64, 1 << 24, False), (h64, 1 << 28, True), (h64, 0, True),
+                              (h511, 131072, False), (h511, 1 << 24, True)):
+        k = sdr.FirPlan(hh, 10, mode=sdr.MODE_FM, size_hint=hint).info()["kernel"]
+        assert (k == "mfma_i8") == want_i8, (hh.size, hint, k)
     rng = np.random.default_rng(5)
     for n in (0, 1, 2, 3, 4, 5, 11, 4097):
         iq = rng.integers(-2048, 2048, 2 * n, dtype=np.int16)

@@ -69,8 +69,8 @@ enum sdr_status {
  *                      Where y[m] is EXACTLY zero the reference's 0 / +-pi (from the signs of its zeros,
  *                      bladerf_apt_demod.cpp:419-421) is reproduced bit for bit by every kernel;
  *                  (3) pipeline 5 only (the int8 matrix kernel, which the automatic choice takes for most
- *                      int16 shapes; pin pipeline 1 or 2 to rule it out): taps below 2^-31 of the largest
- *                      tap vanish in its fixed point.
+ *                      int16 and int8 shapes; pin pipeline 1 or 2 to rule it out): taps below 2^-31 of the
+ *                      largest tap vanish in its fixed point.
  *                      After a run of >= T zero samples in mid-stream, the first output whose window
  *                      meets a non-zero sample ONLY through such taps has y == 0 here and a tiny y in
  *                      the reference: that output and its predecessor report the angle of a zero vector
@@ -95,7 +95,8 @@ enum sdr_input {
                            records, b205_mini/rx_example/src/b205m_rx_main.cpp:54,210); Q11 scale   */
     SDR_IN_I8_IQ = 4    /* interleaved int8 I,Q (HackRF transfer buffers,
                            hackrf/rx_example/src/hackrf_rx_main.cpp:28,54; written as (int8_t) pairs
-                           in hackrf/tx_example/src/hackrf_tx_main.cpp:150-151); scale 1/128        */
+                           in hackrf/tx_example/src/hackrf_tx_main.cpp:150-151); scale 1/128.  Without
+                           mixer these run on the int8 matrix kernel (pipeline 5) like int16 samples */
 };
 
 /* how many decimated samples y[m] = (h * x)[D*m] a block of n_in input samples yields */
@@ -175,9 +176,11 @@ typedef struct sdr_fir_desc {
                              4 = the same float planes, window walk as a Toeplitz GEMM on the
                              matrix cores in float32 (long filters; int16 without mixer only);
                              5 = Toeplitz GEMM on the int8 matrix pipe: samples as their two
-                             bytes, taps as four base-256 digits, exact int32 accumulation
-                             (windows T + 15*D up to 768 samples; at least 2 taps; int16 without
-                             mixer only; leave outputs_per_lane and threads 0; 512 lanes).  An output is
+                             bytes (SDR_IN_I8_IQ: the sample bytes themselves, four byte products per
+                             step instead of seven), taps as four base-256 digits, exact int32
+                             accumulation (windows T + 15*D up to 768 samples; at least 2 taps, 6 for
+                             int8 samples; int16 or int8 input without mixer only; leave
+                             outputs_per_lane and threads 0; 512 lanes).  An output is
                              one exact integer sum over its window: its bits do not depend on tiling,
                              block hand-off or sharding.  Chosen automatically where a measured cost model
                              (tiles vs taps per sample) puts it ahead -- everywhere but small decimation
@@ -196,7 +199,7 @@ typedef struct sdr_fir_desc {
     long long size_hint;  /* 0 = unknown; else the input samples a launch will typically see.  Geometry is
                              chosen for long streams by default; with a hint that says "short" (fewer lane
                              windows than two waves per SIMD) real-input plans take the K-split kernel
-                             (pipeline 6), and int16 plans stay on the vector-unit tile kernels where the
+                             (pipeline 6), and int16 / int8 plans stay on the vector-unit tile kernels where the
                              persistent matrix kernel's ~13 us launch latency would outweigh its rate
                              (blocks below ~2^26 samples at 64 taps / 10, ~2^22 at 511 / 10).  The choice is made once, at plan creation: a plan's outputs do
                              not depend on how a stream is cut into launches. */

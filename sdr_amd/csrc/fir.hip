@@ -1157,7 +1157,7 @@ __device__ __forceinline__ int i8_tile_channel(const FirGeom &g, int t)
 struct I8Tile {
     const unsigned char *vbase;   // the tile's first valid sample (inside the caller's buffer; wave-uniform)
     int lo, hi;                   // valid samples of the tile, tile-relative: [lo, hi)
-    int span4;                    // loads start 0 .. span4 bytes behind vbase: max(4*(hi - 4 - lo), 0)
+    int span;                     // loads start 0 .. span bytes behind vbase: the last one ends at sample hi
     bool edge;                    // some staged sample is outside [lo, hi)
 };
 
@@ -1170,8 +1170,12 @@ __device__ __forceinline__ int i8_clamp_diff(long long d, int n)
     return top < 0 ? 0 : ((top > 0 || low > (unsigned)n) ? n : (int)low);
 }
 
+// S8 = the samples are int8 pairs (2 bytes, SDR_IN_I8_IQ) instead of int16 pairs (4 bytes): a 16-byte
+// load then holds eight samples instead of four
+template <bool S8>
 __device__ __forceinline__ I8Tile i8_tile(const FirGeom &g, const uint32_t *__restrict__ in, int t)
 {
+    constexpr int BPS = S8 ? 2 : 4, SPL = 16 / BPS;
     const int ch = i8_tile_channel(g, t);
     const long long W0 = (g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile) * g.D - g.Tback;
     const int n = 4 * g.s_gran;
@@ -1179,41 +1183,56 @@ __device__ __forceinline__ I8Tile i8_tile(const FirGeom &g, const uint32_t *__re
     int hi = i8_clamp_diff(g.hi_valid - W0, n);
     hi = hi < lo ? lo : hi;
     I8Tile r;
-    r.vbase = (const unsigned char *)(in + (long long)ch * g.in_stride + W0 + lo);
+    r.vbase = (const unsigned char *)in + BPS * ((long long)ch * g.in_stride + W0 + lo);
     r.lo = lo;
     r.hi = hi;
-    r.span4 = 4 * max(hi - 4 - lo, 0);                    // the host refuses streams shorter than 4 samples
+    r.span = BPS * max(hi - SPL - lo, 0);                 // the host refuses streams shorter than one load
     r.edge = lo > 0 || hi < n;
     return r;
 }
 
 __device__ __forceinline__ int i8_med3(int x, int lo, int hi) { return min(max(x, lo), hi); }   // v_med3_i32 (lo <= hi)
 
-// Four samples from tile-relative sample 4*quad, read at the nearest position inside the valid
+// The 16 bytes from tile-relative sample SPL*unit, read at the nearest position inside the valid
 // samples: two vector instructions and a load with a scalar base.
-__device__ __forceinline__ uint4 i8_fetch(const I8Tile &tl, int quad)
+template <bool S8>
+__device__ __forceinline__ uint4 i8_fetch(const I8Tile &tl, int unit)
 {
-    const int off = i8_med3(16 * quad - 4 * tl.lo, 0, tl.span4);
+    constexpr int BPS = S8 ? 2 : 4;
+    const int off = i8_med3(16 * unit - BPS * tl.lo, 0, tl.span);
     return *(const uint4 *)(tl.vbase + (unsigned)off);
 }
 
-// edge tiles: w was loaded at the clamped position; pick / zero the samples the quad asked for
-__device__ __forceinline__ uint4 i8_repair(const I8Tile &tl, int quad, uint4 w)
+// edge tiles: w was loaded at the clamped position; pick / zero the samples the unit asked for
+template <bool S8>
+__device__ __forceinline__ uint4 i8_repair(const I8Tile &tl, int unit, uint4 w)
 {
-    const int rel = 4 * quad;
-    const int at = tl.lo + (i8_med3(16 * quad - 4 * tl.lo, 0, tl.span4) >> 2);
+    constexpr int BPS = S8 ? 2 : 4, SPL = 16 / BPS;
+    const int rel = SPL * unit;
+    const int at = tl.lo + i8_med3(16 * unit - BPS * tl.lo, 0, tl.span) / BPS;
     const uint32_t e[4] = {w.x, w.y, w.z, w.w};
-    uint32_t o[4];
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int si = rel + u, idx = si - at;
+    for (int u = 0; u < SPL; ++u) {
+        const int si = rel + u, idx = si - at;              // sample idx of the loaded 16 bytes, if it is in there
+        const int dw = S8 ? idx >> 1 : idx;
         uint32_t v = e[0];
-        v = idx == 1 ? e[1] : v;
-        v = idx == 2 ? e[2] : v;
-        v = idx == 3 ? e[3] : v;
-        o[u] = (si >= tl.lo && si < tl.hi && idx >= 0 && idx < 4) ? v : 0u;
+        v = dw == 1 ? e[1] : v;
+        v = dw == 2 ? e[2] : v;
+        v = dw == 3 ? e[3] : v;
+        if (S8) v = (idx & 1) ? v >> 16 : v & 0xffffu;
+        v = (si >= tl.lo && si < tl.hi && idx >= 0 && idx < SPL) ? v : 0u;
+        if (S8) o[u >> 1] |= v << (16 * (u & 1));
+        else o[u] = v;
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// eight int8 samples (I | Q << 8 each) -> two dwords per byte plane: {I 0..3, I 4..7}, {Q 0..3, Q 4..7}
+__device__ __forceinline__ void i8_split8(uint4 w, uint2 &pi, uint2 &pq)
+{
+    pi = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x06040200u), __builtin_amdgcn_perm(w.w, w.z, 0x06040200u));
+    pq = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x07050301u), __builtin_amdgcn_perm(w.w, w.z, 0x07050301u));
 }
 
 // four samples (I | Q << 16 each) -> one dword per byte plane: {I lo', I hi, Q lo', Q hi}
@@ -1237,27 +1256,35 @@ __device__ __forceinline__ void i8_split4(uint4 w, uint32_t &il, uint32_t &ih, u
 // angle of an output whose other y is exactly zero, which the reference reports as 0 or +-pi by
 // the signs of its zeros.  One wave per output: the lanes share the taps of y[m] and y[m+1],
 // wave-reduce, lane 0 applies the discriminator.  A few dozen outputs per stream start.
+template <bool S8>
 __device__ __forceinline__ void i8_startup_fm_output(const uint32_t *__restrict__ in, float *__restrict__ out,
                                                      const float *__restrict__ taps, const FirGeom &g,
                                                      long long m, long long ch, int lane)
 {
-    const uint32_t *src = in + ch * g.in_stride;
+    // one sample as (I, Q) floats: an int16 pair (either order) or an int8 pair
+    auto sample = [&](long long s) {
+        if constexpr (S8) {
+            const unsigned w = ((const unsigned short *)in)[ch * g.in_stride + s];
+            return make_float2((float)(signed char)(w & 255u), (float)(signed char)(w >> 8));
+        } else {
+            const uint32_t w = in[ch * g.in_stride + s];
+            return g.swap_iq ? make_float2(hi16(w), lo16(w)) : make_float2(lo16(w), hi16(w));
+        }
+    };
     float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
     const long long n0 = m * g.D, n1 = n0 + g.D;
     for (int k = lane; k < g.T; k += 64) {
         const float h = taps[k];
         const long long s0 = n0 - k, s1 = n1 - k;
         if (s0 >= g.lo_valid && s0 < g.hi_valid) {
-            const uint32_t w = src[s0];
-            const float xi = g.swap_iq ? hi16(w) : lo16(w), xq = g.swap_iq ? lo16(w) : hi16(w);
-            a0.x = __fmaf_rn(h, xi, a0.x);
-            a0.y = __fmaf_rn(h, xq, a0.y);
+            const float2 x = sample(s0);
+            a0.x = __fmaf_rn(h, x.x, a0.x);
+            a0.y = __fmaf_rn(h, x.y, a0.y);
         }
         if (s1 >= g.lo_valid && s1 < g.hi_valid) {
-            const uint32_t w = src[s1];
-            const float xi = g.swap_iq ? hi16(w) : lo16(w), xq = g.swap_iq ? lo16(w) : hi16(w);
-            a1.x = __fmaf_rn(h, xi, a1.x);
-            a1.y = __fmaf_rn(h, xq, a1.y);
+            const float2 x = sample(s1);
+            a1.x = __fmaf_rn(h, x.x, a1.x);
+            a1.y = __fmaf_rn(h, x.y, a1.y);
         }
     }
     a0 = wave_sum(a0);
@@ -1297,7 +1324,9 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
 // NS = k steps of the window, rounded up to a multiple of four (steps past the window carry zero taps
 // and are skipped; the staged tile covers NS steps, so no sample read leaves it).
 // PRE = octets (8 samples) per helper lane and tile: 256 * PRE * 8 samples cover the staged tile.
-template <int NS, int NCB, int PRE>
+// S8 = int8 sample pairs (SDR_IN_I8_IQ): one byte plane per component, four byte products per step
+// (every tap digit with the sample byte; weights 2^0 .. 2^24, no low-byte bias), one 16-byte load per octet.
+template <int NS, int NCB, int PRE, bool S8>
 __global__ void __launch_bounds__(512, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
@@ -1338,7 +1367,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // 128 * (sum of the row's digits), combined over the digits exactly as the accumulators are
         // below: it undoes the -128 of the low bytes, and because the combination is the same sequence
         // of float32 operations on the negated integers, zero samples still give an exact zero
-        const f32x4 bias = __builtin_bit_cast(f32x4, btab[lane]);
+        const f32x4 bias = S8 ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, btab[lane]);
         // hi plane of component j&1, this lane's group within a column block, step 0
         const int bofs = (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq + CBW * wave * (16 * g.D * 8);
         const int cb_bytes = 16 * g.D * 8;                     // between column blocks
@@ -1363,7 +1392,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 for (int u = 0; u < 2 && u < UNITS; ++u) {
                     const unsigned char *bp = bbase + (u / NS) * cb_bytes + 64 * (u % NS);
                     b[u][0] = as_i32x4(*(const uint4 *)bp);
-                    b[u][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
+                    if (!S8) b[u][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
                     if (A0_LDS) b[u][2] = as_i32x4(a0lds[(u % NS) * 64 + lane]);
                 }
                 i32x4 acc[4];                                  // weights 2^8 .. 2^32
@@ -1373,7 +1402,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     if (u + 2 < UNITS && !(SDR_I8_ABL & 32)) {
                         const unsigned char *bp = bbase + ((u + 2) / NS) * cb_bytes + 64 * ((u + 2) % NS);
                         b[(u + 2) % 3][0] = as_i32x4(*(const uint4 *)bp);
-                        b[(u + 2) % 3][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
+                        if (!S8) b[(u + 2) % 3][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
                         if (A0_LDS) b[(u + 2) % 3][2] = as_i32x4(a0lds[((u + 2) % NS) * 64 + lane]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1382,7 +1411,16 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         for (int w = 0; w < 4; ++w) acc[w] = i32x4{0, 0, 0, 0};
                     }
                     if (ks < NS - 3 || ks < g.ngran) {         // wave-uniform
-                        const i32x4 xh = b[u % 3][0], xl = b[u % 3][1];
+                        const i32x4 xh = b[u % 3][0];
+                        const i32x4 a0 = A0_LDS ? b[u % 3][2] : a[ks][0];
+                        if constexpr (S8) {
+                            // one byte per sample: digit w x sample, accumulator w
+                            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, xh, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][1], xh, acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xh, acc[2], 0, 0, 0);
+                            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xh, acc[3], 0, 0, 0);
+                        } else {
+                        const i32x4 xl = b[u % 3][1];
                         // weight w = digit + (hi ? 1 : 0), accumulator w - 1; the weight-0 product (lowest
                         // digit x low byte, < 2^-30 of full scale) is left out: seven products, not eight.
                         // No accumulator twice in a row.
@@ -1390,9 +1428,10 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xl, acc[1], 0, 0, 0);
                         acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xl, acc[2], 0, 0, 0);
                         acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xh, acc[3], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0_LDS ? b[u % 3][2] : a[ks][0], xh, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, xh, acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][1], xh, acc[1], 0, 0, 0);
                         acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xh, acc[2], 0, 0, 0);
+                        }
                     }
                     if (ks == NS - 1) {
                         // y = yscale * sum of 2^(8w) * acc[w] (the common 2^8 sits in yscale): the only
@@ -1427,28 +1466,36 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // raw samples of two tiles travel at any time: set p&1 holds tile p until it is staged in
         // phase p and is then refilled with tile p+2
         constexpr int kI8Pre = PRE;                            // octets per lane and tile held in registers
-        uint4 w0[kI8Pre][2], w1[kI8Pre][2];
+        constexpr int LPO = S8 ? 1 : 2;                        // 16-byte loads per octet
+        uint4 w0[kI8Pre][LPO], w1[kI8Pre][LPO];
         // n-th tile of this workgroup, and its descriptor kept (in scalar registers) until it is staged.
         // Unconditional (past the end: the last tile again, unused): a skipped request would make the
         // registers conditionally defined and hipcc would copy them right after the loads
-        auto request = [&](int n, uint4 (&w)[kI8Pre][2], I8Tile &tl) {
-            tl = i8_tile(g, in, i8_tile_index(n < n_t ? n : n_t - 1));
+        auto request = [&](int n, uint4 (&w)[kI8Pre][LPO], I8Tile &tl) {
+            tl = i8_tile<S8>(g, in, i8_tile_index(n < n_t ? n : n_t - 1));
 #pragma unroll
             for (int k = 0; k < kI8Pre; ++k)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) w[k][h] = i8_fetch(tl, 2 * (256 * k + st) + h);
+                for (int h = 0; h < LPO; ++h) w[k][h] = i8_fetch<S8>(tl, LPO * (256 * k + st) + h);
         };
-        auto phase = [&](int p, uint4 (&w)[kI8Pre][2], I8Tile &tl) {
+        auto phase = [&](int p, uint4 (&w)[kI8Pre][LPO], I8Tile &tl) {
             // (past the last tile: the last one again, into a buffer nobody reads any more -- a skipped
             // staging would leave the set's loads pending on one path into the request below, and hipcc
             // would then wait for every outstanding load, the other set's included, on all paths)
             if (!(SDR_I8_ABL & 2)) {
                 unsigned char *buf = smem + (p & 1) * buf_bytes;
                 auto put = [&](int oct, uint4 q0, uint4 q1) {
+                    unsigned char *dst = buf + 8 * oct;
+                    if constexpr (S8) {                        // q0 holds the octet; the bytes are the planes
+                        uint2 pi, pq;
+                        i8_split8(q0, pi, pq);
+                        *(uint2 *)dst = pi;
+                        *(uint2 *)(dst + plane_bytes) = pq;
+                        return;
+                    }
                     uint32_t il[2], ih[2], ql[2], qh[2];
                     i8_split4(q0, il[0], ih[0], ql[0], qh[0]);
                     i8_split4(q1, il[1], ih[1], ql[1], qh[1]);
-                    unsigned char *dst = buf + 8 * oct;
                     *(uint2 *)(dst + cI * plane_bytes) = make_uint2(ih[0], ih[1]);
                     *(uint2 *)(dst + (1 - cI) * plane_bytes) = make_uint2(qh[0], qh[1]);
                     *(uint2 *)(dst + (2 + cI) * plane_bytes) = make_uint2(il[0], il[1]);
@@ -1462,11 +1509,12 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 #pragma unroll
                     for (int k = 0; k < kI8Pre; ++k)
                         if (256 * k + st < n_oct)
-                            put(256 * k + st, i8_repair(tl, 2 * (256 * k + st), w[k][0]), i8_repair(tl, 2 * (256 * k + st) + 1, w[k][1]));
+                            put(256 * k + st, i8_repair<S8>(tl, LPO * (256 * k + st), w[k][0]),
+                                i8_repair<S8>(tl, LPO * (256 * k + st) + LPO - 1, w[k][LPO - 1]));
                 } else {
 #pragma unroll
                     for (int k = 0; k < kI8Pre; ++k)
-                        if (256 * k + st < n_oct) put(256 * k + st, w[k][0], w[k][1]);
+                        if (256 * k + st < n_oct) put(256 * k + st, w[k][0], w[k][LPO - 1]);
                 }
             }
             clk.mark(0);
@@ -1485,7 +1533,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             const long long n_su = g.store_from - g.out_begin, total = n_su * (g.total_tiles / g.tiles_per_ch);
             for (long long idx = 4LL * blockIdx.x + (st >> 6); idx < total; idx += 4LL * gridDim.x) {
                 const long long ch = idx / n_su;
-                i8_startup_fm_output(in, (float *)outv, ftaps, g, g.out_begin + (idx - ch * n_su), ch, st & 63);
+                i8_startup_fm_output<S8>(in, (float *)outv, ftaps, g, g.out_begin + (idx - ch * n_su), ch, st & 63);
             }
         }
         clk.start();
@@ -1604,13 +1652,14 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
     *what = "fir kernel launch";
     if (p->mfma_i8) {
         const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
-#define SDR_I8P(NS, CB, PRE)                                                                     \
+#define SDR_I8Q(NS, CB, PRE, S8)                                                                 \
     do {                                                                                         \
-        SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE>));                                           \
-        fir_mfma_i8_kernel<NS, CB, PRE><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
+        SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE, S8>));                                       \
+        fir_mfma_i8_kernel<NS, CB, PRE, S8><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale,                 \
                                                                   g.store_from > g.out_begin ? p->d_ftaps : nullptr); \
     } while (0)
+#define SDR_I8P(NS, CB, PRE) do { if (p->input == SDR_IN_I8_IQ) SDR_I8Q(NS, CB, PRE, true); else SDR_I8Q(NS, CB, PRE, false); } while (0)
         // the helper lanes hold a whole staged tile in registers: 4, 6 or 8 octets each (plan creation
         // refuses tiles beyond 256 * 8 octets)
         const int pre = ((p->s_gran + 1) / 2 + 255) / 256;
@@ -1624,6 +1673,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         else SDR_I8(12, 4);
 #undef SDR_I8
 #undef SDR_I8P
+#undef SDR_I8Q
         return hipGetLastError();
     }
     if (p->ksplit) {
@@ -1685,10 +1735,10 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.out_stride = out_stride;
     g.lo_valid = in_first > 0 ? in_first : 0;
     g.hi_valid = (in_first + n_resident < n_total) ? in_first + n_resident : n_total;
-    if (p->mfma_i8 && g.hi_valid - g.lo_valid < 4) {
-        // its staging loads are 4 samples wide and clamped into the valid range
+    if (p->mfma_i8 && g.hi_valid - g.lo_valid < (p->input == SDR_IN_I8_IQ ? 8 : 4)) {
+        // its staging loads are 16 bytes wide (4 int16 or 8 int8 samples) and clamped into the valid range
         if (p->tiny) return launch(p->tiny, in, in_first, n_resident, n_total, out_begin, out_end, in_stride, n_ch, out, out_stride, st);
-        sdr::set_error("pipeline 5 needs at least 4 resident samples");
+        sdr::set_error("pipeline 5 needs at least %d resident samples", p->input == SDR_IN_I8_IQ ? 8 : 4);
         return SDR_EINVAL;
     }
     g.tile0 = out_begin & ~3LL;
@@ -1764,7 +1814,10 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     p->scale = d->scale; p->mix_fr = d->mix_fr; p->count_rule = d->count_rule;
     (void)hipGetDevice(&p->device);
     const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0);
-    if ((d->pipeline == 1 || (d->pipeline >= 3 && d->pipeline <= 5)) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3, 4 and 5 need int16 input without mixer"); return SDR_EINVAL; }
+    // the int8 matrix kernel also takes int8 sample pairs (one byte plane per component)
+    const bool i8_possible = raw_possible || (d->input == SDR_IN_I8_IQ && d->mix_fr == 0.0);
+    if ((d->pipeline == 1 || d->pipeline == 3 || d->pipeline == 4) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3 and 4 need int16 input without mixer"); return SDR_EINVAL; }
+    if (d->pipeline == 5 && !i8_possible) { delete p; sdr::set_error("pipeline 5 needs int16 or int8 input without mixer"); return SDR_EINVAL; }
     const bool ksplit_possible = d->input == SDR_IN_F32_REAL && d->mode != SDR_MODE_FM;
     if (d->pipeline == 6 && !ksplit_possible) { delete p; sdr::set_error("pipeline 6 needs real float input and a mode other than FM"); return SDR_EINVAL; }
     // The planar kernel (float planes, convert once) is an explicit choice only: beyond the int8
@@ -1816,16 +1869,21 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     // The matrix kernel's time follows the number of tiles, not the filter length; it loses where
     // tiles are many and windows short (D <= 4 with few taps).
     bool auto_i8 = false;
-    if (d->pipeline == 0 && raw_possible && !d->outputs_per_lane && !d->threads && d->n_taps >= 2) {
-        const double t_valu = std::fmax(0.256, 0.17 + 0.0125 * (double)d->n_taps / (double)d->decim);
+    const bool s8 = d->input == SDR_IN_I8_IQ;
+    if (d->pipeline == 0 && i8_possible && !d->outputs_per_lane && !d->threads && d->n_taps >= (s8 ? 6 : 2)) {
+        // int8 sample pairs (tools/sweep_int8_input.py, eighteen shapes): the float-tile kernel is the
+        // alternative, max(0.30, 0.25 + 0.02 * T/D); a matrix tile takes 0.95 + 0.06 * steps + 0.03 * D
+        // microseconds (four byte products per step instead of seven, half the bytes per sample)
+        const double tpd = (double)d->n_taps / (double)d->decim;
+        const double t_valu = s8 ? std::fmax(0.30, 0.25 + 0.02 * tpd) : std::fmax(0.256, 0.17 + 0.0125 * tpd);
         const int Wn = roundup(d->n_taps - 1, 4) + 15 * d->decim + 1;
         const int nks = (Wn + 63) / 64, steps = (nks + 3) / 4;
         const long long s_big = 16LL * d->decim * 63 + 256LL * steps;
         const bool big = s_big <= 8 * 256 * 8 &&
                          2 * 4 * (roundup((int)s_big, 256) + 240) + 2 * 8 * kI8PartSlots * 16 + (steps > 2 ? 12 * 1024 : 0) <= 160 * 1024;
-        const double tile_us = (0.7 + 0.112 * nks + 0.085 * d->decim) * (big ? 1.0 : 0.55);
+        const double tile_us = (s8 ? 0.95 + 0.06 * nks + 0.03 * d->decim : 0.7 + 0.112 * nks + 0.085 * d->decim) * (big ? 1.0 : 0.55);
         const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
-        const double t_hbm = (4.0 + 4.0 / d->decim) * 268435456.0 / 5.4e12 * 1e3;
+        const double t_hbm = ((s8 ? 2.0 : 4.0) + 4.0 / d->decim) * 268435456.0 / 5.4e12 * 1e3;
         const double t_i8 = std::fmax(t_hbm, tiles_per_cu * tile_us * 1e-3);
         auto_i8 = t_i8 < t_valu;
         if (d->size_hint > 0) {
@@ -1836,11 +1894,12 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             auto_i8 = 0.013 + t_i8 * f < 0.004 + t_valu * f;
         }
     }
-    if (d->pipeline == 5 && d->n_taps < 2) {
-        // no history halo: a tile at the stream's end could hold fewer than the four valid samples its
-        // 16-byte staging loads need, and a one-tap "filter" has nothing for the matrix pipe anyway
+    if (d->pipeline == 5 && d->n_taps < (s8 ? 6 : 2)) {
+        // no history halo: a tile at the stream's end could hold fewer than the four (int8 input: eight)
+        // valid samples its 16-byte staging loads need, and a one-tap "filter" has nothing for the matrix
+        // pipe anyway
         delete p;
-        sdr::set_error("pipeline 5 needs at least 2 taps");
+        sdr::set_error("pipeline 5 needs at least %d taps", s8 ? 6 : 2);
         return SDR_EINVAL;
     }
     if (d->pipeline == 5 || auto_i8) {
@@ -2073,7 +2132,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const int F = 30 - e2;                                 // |q| <= 2^30
         std::vector<long long> q(p->T);
         for (int i = 0; i < p->T; ++i) q[i] = std::llround(std::ldexp(d->taps[i], F));
-        p->yscale = (float)std::ldexp(1.0, -(F + 11) + 8);     // Q11 samples; the kernel's sums start at weight 2^8
+        // Q11 samples, the kernel's sums start at weight 2^8 (int16) | Q7 samples, sums from weight 2^0 (int8)
+        p->yscale = (float)std::ldexp(1.0, p->input == SDR_IN_I8_IQ ? -(F + 7) : -(F + 11) + 8);
         std::vector<int> rowsum((size_t)4 * 16, 0);            // [digit][row]
         at8.assign((size_t)kI8MaxSteps * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
         {
@@ -2132,7 +2192,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     }
     if (p->mfma_i8 && d->pipeline == 0) {
         sdr_fir_desc d2 = *d;
-        d2.pipeline = 1;                                       // raw tile
+        d2.pipeline = d->input == SDR_IN_I8_IQ ? 2 : 1;        // float tiles | raw tile
         if (sdr_fir_plan_create(&d2, &p->tiny) != SDR_OK) p->tiny = nullptr;
     }
     *out = p;

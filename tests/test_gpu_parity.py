@@ -10,6 +10,8 @@ full scale on float32 outputs):
                   ill-conditioned angles and get 1e-3*FS; outputs that are exact zeros / +-pi in
                   the reference (y exactly zero) must match exactly.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -404,7 +406,8 @@ def test_fft_exact_zero_gives_minus_inf(sdr):
 @pytest.mark.gpu
 def test_wire_formats(sdr, oracle):
     """Q-first int16 (B205 recordings) on every kernel, int8 pairs (HackRF) on the
-    streaming kernel, against the oracle chain run on the unpacked samples."""
+    streaming kernel (test_int8_samples_on_the_matrix_kernel: on the matrix kernel), against the oracle
+    chain run on the unpacked samples."""
     rng = np.random.default_rng(77)
     n = 200_003
     T, D = 64, 10
@@ -438,11 +441,11 @@ def test_wire_formats(sdr, oracle):
     fm8 = oracle.polar_discriminator(y8, 1 / TWO_PI)
     for R, NT in ((0, 0), (1, 64), (4, 128)):
         tag = f"int8 R={R} NT={NT}"
-        p = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I8_IQ, outputs_per_lane=R, threads=NT)
+        p = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I8_IQ, outputs_per_lane=R, threads=NT, pipeline=2)
         assert p.info()["kernel"] == "stream"
         check_fm(p.execute_host(b), fm8, y8, 1 / TWO_PI, tag)
         check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_I8_IQ, outputs_per_lane=R,
-                                 threads=NT).execute_host(b), np.abs(y8), tag)
+                                 threads=NT, pipeline=2).execute_host(b), np.abs(y8), tag)
         check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=sdr.IN_I8_IQ, outputs_per_lane=R,
                                  threads=NT).execute_host(b), y8, tag)
     # odd byte address (sample-aligned only): the checked path
@@ -695,6 +698,48 @@ def test_int8_matrix_kernel_instantiations(sdr, oracle, T, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,D", [(64, 10), (64, 4), (24, 15), (200, 10), (255, 4), (195, 15), (511, 10), (600, 4), (511, 15),
+                                 (101, 20), (300, 25), (40, 30), (511, 16)])      # D >= 16: tiles of 512 outputs
+def test_int8_samples_on_the_matrix_kernel(sdr, oracle, T, D):
+    """HackRF int8 pairs (hackrf_rx_main.cpp:28,54) on the int8 matrix kernel: the sample bytes are the
+    operand planes, four byte products per step.  All modes against the oracle on full-range bytes
+    with ragged ends, at an odd byte offset inside the device buffer, in two time shards (bit-identical
+    to the one-piece run), and the automatic choice."""
+    rng = np.random.default_rng(T * 31 + D)
+    n = 3 * 1024 * D + 5 * D + 3 + T
+    b = rng.integers(-128, 128, 2 * n).astype(np.int8)
+    ph = 2 * np.pi * np.cumsum(0.01 + 0.004 * np.sin(2 * np.pi * 1e-3 * np.arange(n)))
+    b[0::2] = np.clip(np.rint(90 * np.cos(ph)) + rng.integers(-38, 39, n), -128, 127).astype(np.int8)
+    b[1::2] = np.clip(np.rint(90 * np.sin(ph)) + rng.integers(-38, 39, n), -128, 127).astype(np.int8)
+    h = oracle.create_fir_filter(T, 0.8 / D, "hann")
+    y = oracle.fir_decimate(oracle.unpack_scale_i8(b), D, h)
+    fm = oracle.polar_discriminator(y, 1 / TWO_PI)
+    for mode, want in ((sdr.MODE_IQ, y), (sdr.MODE_ENV, np.abs(y))):
+        plan = sdr.FirPlan(h, D, mode=mode, input=sdr.IN_I8_IQ, pipeline=5)
+        assert plan.info()["kernel"] == "mfma_i8"
+        check_linear(plan.execute_host(b), want, f"int8 on i8 {T}/{D} mode {mode}")
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I8_IQ, pipeline=5)
+    one = plan.execute_host(b)
+    check_fm(one, fm, y, 1 / TWO_PI, f"int8 on i8 {T}/{D} fm")
+    # the stream at an odd sample offset inside a device buffer (2-byte aligned 16-byte loads), two shards
+    cnt = plan.out_count(n)
+    d_all = sdr.DevBuf(2 * (n + 16))
+    sdr.capi.check(sdr.capi.lib().sdr_dev_upload(d_all.at(2 * 3), b.ctypes.data_as(C.c_void_p), C.c_size_t(2 * n)))
+    parts = []
+    for ob, oe in ((0, cnt // 2), (cnt // 2, cnt)):
+        lo = max(0, ob * D - (T - 1))
+        hi = min(n, (oe + 1) * D + 1)
+        d_out = sdr.DevBuf(max(oe - ob, 1) * 4)
+        plan.execute_range_dev(d_all.at(2 * (3 + lo)), lo, hi - lo, n, ob, oe, d_out)
+        sdr.sync()
+        parts.append(d_out.to_numpy(np.float32, oe - ob))
+    assert np.array_equal(np.concatenate(parts), one)
+    # the automatic choice: the matrix kernel or, for few taps per output, the float tiles
+    auto = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I8_IQ).info()["kernel"]
+    assert auto in ("mfma_i8", "stream"), auto
+
+
+@pytest.mark.gpu
 def test_int8_matrix_kernel_shards_and_channels(sdr, oracle):
     """the int8 matrix kernel behind the other entry points: time shards with their history halo
     (tiles that start before / end after the resident window), channel-major batches (tiles of
@@ -837,7 +882,7 @@ def test_randomised_shapes(sdr, oracle):
         try:
             ran += fuzz_parity.one_case(np.random.default_rng(seed), seed) == "ok"
         except sdr.SdrError as e:
-            assert "pipeline 5 needs at least 4 resident samples" in str(e), (seed, str(e))
+            assert "pipeline 5 needs at least" in str(e) and "resident samples" in str(e), (seed, str(e))
     assert ran >= 300
 
 

@@ -97,7 +97,8 @@ def stream_case(rng, seed):
     if got.size == 0:
         return
     # Bit-identical to the one-shot launch for the vector-unit kernels without mixer (one summation
-    # order per output whatever the tiling).  The int8 matrix kernel rounds once per tile position and
+    # order per output whatever the tiling).  An automatic plan on the int8 matrix kernel (exact integer
+    # sums) hands launches with fewer resident samples than that kernel takes to a float kernel, and
     # the mixer's phasor is a product that starts at the tile's first sample, so there the blocks'
     # outputs are held to the tolerance (discriminator: to the oracle with the conditioned bound).
     loose = plan.info()["kernel"] == "mfma_i8" or mix != 0.0
@@ -140,7 +141,7 @@ def batched_case(rng, seed):
     try:
         plan.execute_batched_dev(d_in, n, stride_in, n_ch, d_out, stride_out)
     except sdr.SdrError as e:
-        assert pipe == 5 and "at least 4" in str(e), tag + str(e)
+        assert pipe == 5 and "resident samples" in str(e), tag + str(e)
         return
     sdr.sync()
     out = d_out.to_numpy(dt, stride_out * n_ch)
@@ -149,12 +150,7 @@ def batched_case(rng, seed):
     for c in sorted(set([0, n_ch - 1, int(rng.integers(0, n_ch))])):
         one = plan.execute_host(buf[2 * c * stride_in: 2 * (c * stride_in + n)])
         got = out[c * stride_out: c * stride_out + cnt]
-        if plan.info()["kernel"] == "mfma_i8":
-            if mode == sdr.MODE_FM:
-                continue            # noise input: angles ill-conditioned, tile positions differ
-            assert np.abs(got - one).max() <= 2e-6 * max(1.0, float(np.abs(one).max())), tag + f" ch {c}"
-        else:
-            assert np.array_equal(got, one), tag + f" ch {c}"
+        assert np.array_equal(got, one), tag + f" ch {c} kernel {plan.info()['kernel']}"
     plan.destroy()
 
 

@@ -64,7 +64,10 @@ def one_case(rng, case_seed):
         n = min(n, 40_000)
     mix = float(rng.choice([0.0, 0.0, 0.0371, -0.123]))
     pipe = int(rng.choice([0, 0, 0, 1, 2, 3, 5]))
-    if (mix != 0.0 or kind not in (sdr.IN_I16_IQ, sdr.IN_I16_QI)) and pipe not in (0, 2):
+    matrix_ok = mix == 0.0 and kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ)
+    if pipe == 5 and not matrix_ok:
+        pipe = 0
+    if (mix != 0.0 or kind not in (sdr.IN_I16_IQ, sdr.IN_I16_QI)) and pipe not in (0, 2, 5):
         pipe = 0
     h = random_taps(rng, T, D)
     scale = float(rng.choice([1 / TWO_PI, 0.75, -1.0]))
@@ -83,7 +86,11 @@ def one_case(rng, case_seed):
             raw = np.empty_like(iq)
             raw[0::2], raw[1::2] = iq[1::2], iq[0::2]
     elif kind == sdr.IN_I8_IQ:
-        raw = rng.integers(-128, 128, 2 * n, dtype=np.int8)
+        if mode == sdr.MODE_FM and n > 0:
+            raw = oracle.synth_fm_i16(n, fs=1.0e6, ftone=3000.0, dev=20000.0, amp=100.0)
+            raw = (raw + rng.integers(-3, 4, raw.size)).astype(np.int8)
+        else:
+            raw = rng.integers(-128, 128, 2 * n, dtype=np.int8)
         x = (raw[0::2].astype(np.float64) + 1j * raw[1::2].astype(np.float64)) / 128.0
     elif kind == sdr.IN_CF32:
         raw = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3).astype(np.complex64)
@@ -122,7 +129,7 @@ def one_case(rng, case_seed):
         check_linear(got, np.ascontiguousarray(y.real), tag)
     else:
         want = oracle.polar_discriminator(y, scale)
-        if kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI) and mix == 0.0:
+        if kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ) and mix == 0.0:
             check_fm(got, want, y, scale, tag)
         else:
             assert got.shape == want.shape, tag     # noise input: angles are ill-conditioned; shape only
@@ -145,7 +152,7 @@ def one_case(rng, case_seed):
         assert np.all(back[: oo * w] == 0x7FC0DEAD) and np.all(back[(oo + cnt) * w:] == 0x7FC0DEAD), tag + f" wrote outside its outputs (so={so} oo={oo})"
         assert np.array_equal(back[oo * w: (oo + cnt) * w], got.view(np.uint32).reshape(-1)), tag + f" differs at pointer offsets so={so} oo={oo}"
     # a random shard cut of the same stream must reproduce the whole
-    int_kind = kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI)
+    int_kind = kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ) and mix == 0.0
     per = 2 if kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ) else 1      # array elements per sample
     if cnt >= 2 and (int_kind or mode != sdr.MODE_FM):
         ob = int(rng.integers(0, cnt - 1))
@@ -194,7 +201,7 @@ def main():
             n_bad += 1
             print("FAIL", str(e)[:400], flush=True)
         except sdr.SdrError as e:
-            if "pipeline 5 needs at least 4 resident samples" in str(e):
+            if "pipeline 5 needs at least" in str(e) and "resident samples" in str(e):
                 n_ref += 1           # documented limit of the explicit choice (automatic plans delegate)
                 continue
             n_bad += 1

@@ -1342,6 +1342,8 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     // phases: tile t is staged in phase t, multiplied in t+1, finished in t+2; an even count, so that
     // the helper waves' loop over their two register sets has no conditional half
     const int n_ph = (n_t + 3) & ~1;
+    // who finishes: 0 the matrix waves, 1 the helper waves, 2 both (one half of the tile each; see the matrix waves)
+    constexpr int FIN = (NCB == 8 && PRE <= (S8 ? 6 : 4)) ? 2 : 0;
     I8Clock clk;
 
     if (matrix) {
@@ -1375,21 +1377,29 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // Measured alternatives, all within 2 %: finishing in the helper waves (they are then the longer
         // role), half in each, and its arithmetic interleaved with the MFMAs by sched_group_barrier --
         // MFMA and vector time of a SIMD add up whichever wave issues them.
+        // Narrow tiles leave the helper waves little to stage: there each role finishes one half of the
+        // tile (FIN = 2: 512 finishing lanes).  int16 samples: tiles of up to four octets per helper
+        // lane (D <= 7; same box, 2^28 samples: 32/2 0.600 -> 0.557 ms, 255/4 0.408 -> 0.392, 700/4
+        // 0.616 -> 0.591; at D = 10 it would lose 8 %).  int8 samples -- four products per step instead
+        // of seven, half the bytes to split, both roles short: up to six octets (D <= 10; 32/2 0.565 ->
+        // 0.495, 255/4 0.341 -> 0.306, 511/10 0.194 -> 0.183; wider tiles lose 5-10 % that way).
         constexpr int R = NCB / 2;
         clk.start();
         for (int p = 0; p < n_ph; ++p) {
             // the tile before the last
-            if (p >= 2 && p - 2 < n_t && !(SDR_I8_ABL & 4))
-                i8_finish<R, NCB>(g, outv, (const float *)ybuf, p & 1, tid, p - 2);
+            if (FIN != 1 && p >= 2 && p - 2 < n_t && !(SDR_I8_ABL & 4))
+                i8_finish<(FIN == 2 ? R / 2 : R), NCB>(g, outv, (const float *)ybuf, p & 1, tid, p - 2);
             clk.mark(2);
             const bool work = p >= 1 && p <= n_t && !(SDR_I8_ABL & 1);
             if (work) {
                 const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs;
-                // units of (column block, step), samples requested two units ahead
+                // units of (column block, step), samples requested PD units ahead (int8 samples: a unit
+                // is four MFMAs, 64 cycles, so the LDS round trip needs the longer lead)
                 constexpr int UNITS = CBW * NS;
-                i32x4 b[3][3];                                 // [buffer][hi, lo, lowest tap digit]
+                constexpr int PD = S8 ? 4 : 2, NB = PD + 1;
+                i32x4 b[NB][3];                                // [buffer][hi, lo, lowest tap digit]
 #pragma unroll
-                for (int u = 0; u < 2 && u < UNITS; ++u) {
+                for (int u = 0; u < PD && u < UNITS; ++u) {
                     const unsigned char *bp = bbase + (u / NS) * cb_bytes + 64 * (u % NS);
                     b[u][0] = as_i32x4(*(const uint4 *)bp);
                     if (!S8) b[u][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
@@ -1399,11 +1409,11 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 #pragma unroll
                 for (int u = 0; u < UNITS; ++u) {
                     const int cb = u / NS, ks = u % NS;
-                    if (u + 2 < UNITS && !(SDR_I8_ABL & 32)) {
-                        const unsigned char *bp = bbase + ((u + 2) / NS) * cb_bytes + 64 * ((u + 2) % NS);
-                        b[(u + 2) % 3][0] = as_i32x4(*(const uint4 *)bp);
-                        if (!S8) b[(u + 2) % 3][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
-                        if (A0_LDS) b[(u + 2) % 3][2] = as_i32x4(a0lds[((u + 2) % NS) * 64 + lane]);
+                    if (u + PD < UNITS && !(SDR_I8_ABL & 32)) {
+                        const unsigned char *bp = bbase + ((u + PD) / NS) * cb_bytes + 64 * ((u + PD) % NS);
+                        b[(u + PD) % NB][0] = as_i32x4(*(const uint4 *)bp);
+                        if (!S8) b[(u + PD) % NB][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
+                        if (A0_LDS) b[(u + PD) % NB][2] = as_i32x4(a0lds[((u + PD) % NS) * 64 + lane]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks == 0) {
@@ -1411,8 +1421,8 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         for (int w = 0; w < 4; ++w) acc[w] = i32x4{0, 0, 0, 0};
                     }
                     if (ks < NS - 3 || ks < g.ngran) {         // wave-uniform
-                        const i32x4 xh = b[u % 3][0];
-                        const i32x4 a0 = A0_LDS ? b[u % 3][2] : a[ks][0];
+                        const i32x4 xh = b[u % NB][0];
+                        const i32x4 a0 = A0_LDS ? b[u % NB][2] : a[ks][0];
                         if constexpr (S8) {
                             // one byte per sample: digit w x sample, accumulator w
                             acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, xh, acc[0], 0, 0, 0);
@@ -1420,7 +1430,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                             acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xh, acc[2], 0, 0, 0);
                             acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xh, acc[3], 0, 0, 0);
                         } else {
-                        const i32x4 xl = b[u % 3][1];
+                        const i32x4 xl = b[u % NB][1];
                         // weight w = digit + (hi ? 1 : 0), accumulator w - 1; the weight-0 product (lowest
                         // digit x low byte, < 2^-30 of full scale) is left out: seven products, not eight.
                         // No accumulator twice in a row.
@@ -1520,6 +1530,8 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             clk.mark(0);
             request(p + 2, w, tl);
             clk.mark(1);
+            if (FIN != 0 && p >= 2 && p - 2 < n_t && !(SDR_I8_ABL & 4))
+                i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, p - 2);
             clk.arrive();
             lds_only_barrier();
             clk.leave();
@@ -1872,16 +1884,18 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     const bool s8 = d->input == SDR_IN_I8_IQ;
     if (d->pipeline == 0 && i8_possible && !d->outputs_per_lane && !d->threads && d->n_taps >= (s8 ? 6 : 2)) {
         // int8 sample pairs (tools/sweep_int8_input.py, eighteen shapes): the float-tile kernel is the
-        // alternative, max(0.30, 0.25 + 0.02 * T/D); a matrix tile takes 0.95 + 0.06 * steps + 0.03 * D
-        // microseconds (four byte products per step instead of seven, half the bytes per sample)
+        // alternative, max(0.30, 0.25 + 0.02 * T/D, 0.2 + 0.85 / D); a matrix tile takes
+        // 0.78 + 0.06 * steps + 0.045 * D microseconds (four byte products per step instead of seven,
+        // half the bytes per sample)
         const double tpd = (double)d->n_taps / (double)d->decim;
-        const double t_valu = s8 ? std::fmax(0.30, 0.25 + 0.02 * tpd) : std::fmax(0.256, 0.17 + 0.0125 * tpd);
+        const double t_valu = s8 ? std::fmax(std::fmax(0.30, 0.25 + 0.02 * tpd), 0.2 + 0.85 / d->decim)
+                                 : std::fmax(0.256, 0.17 + 0.0125 * tpd);
         const int Wn = roundup(d->n_taps - 1, 4) + 15 * d->decim + 1;
         const int nks = (Wn + 63) / 64, steps = (nks + 3) / 4;
         const long long s_big = 16LL * d->decim * 63 + 256LL * steps;
         const bool big = s_big <= 8 * 256 * 8 &&
                          2 * 4 * (roundup((int)s_big, 256) + 240) + 2 * 8 * kI8PartSlots * 16 + (steps > 2 ? 12 * 1024 : 0) <= 160 * 1024;
-        const double tile_us = (s8 ? 0.95 + 0.06 * nks + 0.03 * d->decim : 0.7 + 0.112 * nks + 0.085 * d->decim) * (big ? 1.0 : 0.55);
+        const double tile_us = (s8 ? 0.78 + 0.06 * nks + 0.045 * d->decim : 0.7 + 0.112 * nks + 0.085 * d->decim) * (big ? 1.0 : 0.55);
         const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
         const double t_hbm = ((s8 ? 2.0 : 4.0) + 4.0 / d->decim) * 268435456.0 / 5.4e12 * 1e3;
         const double t_i8 = std::fmax(t_hbm, tiles_per_cu * tile_us * 1e-3);

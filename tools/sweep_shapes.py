@@ -8,10 +8,11 @@ n = 1 << 28
 d_in = sdr_amd.DevBuf(n * 4 + 64)
 sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=20e6, noise_lsb=8)
 d_out = sdr_amd.DevBuf(n * 4 + 64)
-for (T, D) in ((64, 10), (64, 4), (101, 5), (101, 20), (128, 8), (128, 16), (200, 10), (195, 15), (300, 7), (255, 4), (300, 25), (400, 12), (511, 10), (511, 15), (700, 4)):
+PIPES = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 3, 5)
+for (T, D) in ((64, 10), (64, 4), (32, 2), (101, 5), (101, 20), (128, 8), (128, 16), (200, 10), (195, 15), (300, 7), (255, 4), (300, 25), (400, 12), (511, 10), (511, 15), (700, 4)):
     h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
     row = []
-    for pipe in (1, 3, 5):
+    for pipe in PIPES:
         try:
             p = sdr_amd.FirPlan(h, D, mode=sdr_amd.MODE_FM, pipeline=pipe)
         except sdr_amd.SdrError as e:

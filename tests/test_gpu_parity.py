@@ -740,6 +740,55 @@ def test_int8_samples_on_the_matrix_kernel(sdr, oracle, T, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,D", [(64, 10), (101, 4), (300, 20)])
+def test_int8_samples_channels_and_blocks(sdr, oracle, T, D):
+    """int8 pairs on the matrix kernel behind the other entry points: channel-major batches with odd
+    strides (2-byte aligned channel starts) equal the channels run one by one, and blocks pushed
+    through the stream hand-off equal the one-shot launch -- bit for bit, the sums are exact integers."""
+    rng = np.random.default_rng(T + D)
+    h = oracle.create_fir_filter(T, 0.8 / D, "hann")
+    n_ch, n = 5, 2 * 1024 * D + 3 * D + 1
+    stride_in = n + 3
+    buf = rng.integers(-128, 128, 2 * stride_in * n_ch, dtype=np.int8)
+    for mode, dt, eb in ((sdr.MODE_FM, np.float32, 4), (sdr.MODE_IQ, np.complex64, 8)):
+        plan = sdr.FirPlan(h, D, mode=mode, input=sdr.IN_I8_IQ, pipeline=5)
+        cnt = plan.out_count(n)
+        stride_out = cnt + 1
+        d_in = sdr.DevBuf.from_numpy(buf)
+        d_out = sdr.DevBuf.from_numpy(np.full(stride_out * n_ch * (eb // 4), 0x7FC0DEAD, np.uint32))
+        plan.execute_batched_dev(d_in, n, stride_in, n_ch, d_out, stride_out)
+        sdr.sync()
+        out = d_out.to_numpy(dt, stride_out * n_ch)
+        for c in range(n_ch):
+            one = plan.execute_host(buf[2 * c * stride_in: 2 * (c * stride_in + n)])
+            assert np.array_equal(out[c * stride_out: c * stride_out + cnt], one), (mode, c)
+            pad = out[c * stride_out + cnt: (c + 1) * stride_out].view(np.uint32)
+            assert np.all(pad == 0x7FC0DEAD), (mode, c)
+        if mode == sdr.MODE_IQ:
+            y = oracle.fir_decimate(oracle.unpack_scale_i8(buf[2 * 2 * stride_in: 2 * (2 * stride_in + n)]), D, h)
+            check_linear(out[2 * stride_out: 2 * stride_out + cnt], y, f"int8 batch {T}/{D}")
+    # blocks through the hand-off
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_I8_IQ, pipeline=5)
+    b = buf[: 2 * stride_in * 3]
+    nb = b.size // 2
+    whole = plan.execute_host(b)
+    stream = sdr.FirStream(plan, 8192)
+    pos, parts, in_flight = 0, [], 0
+    while pos < nb:
+        blk = int(min(nb - pos, rng.choice([8192, 4096, 1000, 37, 9, 8191])))
+        stream.push(b[2 * pos: 2 * (pos + blk)])
+        pos += blk
+        in_flight += 1
+        if in_flight == 2:
+            parts.append(stream.pop())
+            in_flight -= 1
+    while in_flight:
+        parts.append(stream.pop())
+        in_flight -= 1
+    assert np.array_equal(np.concatenate(parts), whole)
+
+
+@pytest.mark.gpu
 def test_int8_matrix_kernel_shards_and_channels(sdr, oracle):
     """the int8 matrix kernel behind the other entry points: time shards with their history halo
     (tiles that start before / end after the resident window), channel-major batches (tiles of

@@ -193,10 +193,17 @@ __device__ __forceinline__ void store_outputs(const FirGeom &g, void *__restrict
     const long long out_end = tile_end < g.out_end ? tile_end : g.out_end;   // this tile's share ends here
     if (g.mode == SDR_MODE_IQ) {
         float2 *out = (float2 *)outv + ch * g.out_stride;
+        float2 *dst = out + (m0 - g.out_begin);
+        // two outputs per 16-byte store where the lane's run is whole and aligned
+        if (R >= 2 && m0 >= g.store_from && m0 + R <= out_end && (((uintptr_t)dst) & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r + 1 < R; r += 2) nt_store((float *)(dst + r), y[r].x, y[r].y, y[r + 1].x, y[r + 1].y);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const long long j = m0 + r;
-            if (j >= g.store_from && j < out_end) nt_store((float *)(out + (j - g.out_begin)), y[r].x, y[r].y);
+            if (j >= g.store_from && j < out_end) nt_store((float *)(dst + r), y[r].x, y[r].y);
         }
         return;
     }
@@ -1306,6 +1313,22 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
     const int t = i8_tile_index(n);
     const int ch = i8_tile_channel(g, t);
     const long long M0 = g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile;
+    if (RH > 2 && g.mode == SDR_MODE_IQ) {
+        // complex outputs need no neighbour: lane F takes the pairs 2*F + j * (2 * lanes), so that every
+        // store instruction of a wave writes 1 KB of consecutive bytes (RH consecutive outputs per lane
+        // are 8 * RH bytes apart between lanes, and those partial lines cost 2x on the int8 kernel's
+        // 4-output lanes: 0.43 against 0.21 ms per 2^28 samples at 64 taps / 10)
+        constexpr int NL = TILE / RH;
+#pragma unroll
+        for (int jp = 0; jp < RH / 2; ++jp) {
+            const int o = 2 * NL * jp + 2 * F;
+            const float *pp = ybuf + par * NCB * (4 * kI8PartSlots) + (o >> 7) * (4 * kI8PartSlots) + (o & 127);
+            const float2 qi = *(const float2 *)pp, qq = *(const float2 *)(pp + 4 * 33);
+            const float2 yy[2] = {make_float2(qi.x, qq.x), make_float2(qi.y, qq.y)};
+            store_outputs<2>(g, outv, ch, M0 + (long long)o, yy, yy[1], M0 + g.per_tile);
+        }
+        return;
+    }
     float2 y[RH], ynext;
     if constexpr (RH == 4) {
         const float4 qi = *(const float4 *)pa, qq = *(const float4 *)(pa + 4 * 33);

@@ -20,13 +20,13 @@ build)
   done ;;
 run)
   for r in 1 2; do
-    echo -n "shipped  "; timeout -k 10 120 python3 tools/run_one.py ${LOG2N:-28} 511 10 1 0 0 5 20 | cut -c1-30 || exit 1
+    echo -n "shipped  "; timeout -k 10 120 python3 tools/run_one.py ${LOG2N:-28} ${TD:-511 10} 1 0 0 5 20 | cut -c1-30 || exit 1
     for v in $VARS; do
       echo -n "ablate=$v  "
       if [ $v = 8 ]; then
-        SDRHIP_LIB=$PWD/tools/exp/libsdrhip_i8abl$v.so timeout -k 10 120 python3 tools/i8_stamps.py ${LOG2N:-28} || exit 1
+        SDRHIP_LIB=$PWD/tools/exp/libsdrhip_i8abl$v.so timeout -k 10 120 python3 tools/i8_stamps.py ${LOG2N:-28} ${TD:-511 10} || exit 1
       else
-        SDRHIP_LIB=$PWD/tools/exp/libsdrhip_i8abl$v.so timeout -k 10 120 python3 tools/run_one.py ${LOG2N:-28} 511 10 1 0 0 5 20 | cut -c1-30 || exit 1
+        SDRHIP_LIB=$PWD/tools/exp/libsdrhip_i8abl$v.so timeout -k 10 120 python3 tools/run_one.py ${LOG2N:-28} ${TD:-511 10} 1 0 0 5 20 | cut -c1-30 || exit 1
       fi
     done
   done ;;

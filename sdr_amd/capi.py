@@ -41,7 +41,12 @@ class FirDesc(C.Structure):
 # the register pairs); the FIR walk gains from v_pk_fma_f32 and keeps the default
 # fft_wave.hip (one 4096-point frame per wavefront) is bound by vector-instruction issue: the max-ILP
 # scheduling strategy leaves fewer dependent-issue stalls there (0.723 vs 0.734 ms per 2^28 samples)
-EXTRA_FLAGS = {"fft.hip": ["-fno-slp-vectorize"],
+# fir.hip: the int8 matrix kernel draws its tiles from an atomic counter one phase ahead; LLVM's atomic
+# optimizer would rewrite that one-lane atomic into a wave-wide form that reads the result back at once
+# (s_waitcnt vmcnt(0) right behind the atomic: the round trip, and the acknowledgements of the stores
+# before it, in every phase).  Results do not depend on the flag, only the kernel's speed.
+EXTRA_FLAGS = {"fir.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+               "fft.hip": ["-fno-slp-vectorize"],
                "fft_wave.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
@@ -225,7 +230,19 @@ class FirPlan:
                                          C.byref(n_out)))
         return out[: n_out.value]
 
+    def _in_bytes(self):
+        return {IN_I16_IQ: 4, IN_I16_QI: 4, IN_I8_IQ: 2, IN_CF32: 8}.get(self.input, 4)
+
+    def _fits(self, what, buf, need_bytes):
+        """The C ABI trusts the caller's device pointers.  When a buffer is a DevBuf its size is known
+        here, so a launch that would read or write past it is refused on the host (an undersized
+        output buffer in a measurement script is a GPU memory fault otherwise)."""
+        if isinstance(buf, DevBuf) and need_bytes > buf.nbytes:
+            raise ValueError(f"{what}: the launch needs {need_bytes} bytes, the DevBuf holds {buf.nbytes}")
+
     def execute_dev(self, d_in, n_in, d_out, out_capacity, stream=None):
+        self._fits("input", d_in, n_in * self._in_bytes())
+        self._fits("output", d_out, min(out_capacity, self.out_count(n_in)) * np.dtype(self.out_dtype).itemsize)
         n_out = C.c_size_t()
         check(lib().sdr_fir_execute_dev(self.h, _vp(d_in), C.c_size_t(n_in), _vp(d_out),
                                         C.c_size_t(out_capacity), C.byref(n_out),
@@ -234,6 +251,8 @@ class FirPlan:
 
     def execute_range_dev(self, d_in, in_first, n_resident, n_total, out_begin, out_end, d_out,
                           stream=None):
+        self._fits("input", d_in, n_resident * self._in_bytes())
+        self._fits("output", d_out, max(out_end - out_begin, 0) * np.dtype(self.out_dtype).itemsize)
         check(lib().sdr_fir_execute_range_dev(self.h, _vp(d_in), C.c_uint64(in_first),
                                               C.c_uint64(n_resident), C.c_uint64(n_total),
                                               C.c_uint64(out_begin), C.c_uint64(out_end),
@@ -241,6 +260,10 @@ class FirPlan:
 
     def execute_batched_dev(self, d_in, n_in, in_stride, n_channels, d_out, out_stride,
                             stream=None):
+        cnt = self.out_count(n_in)
+        if n_channels > 0:
+            self._fits("input", d_in, ((n_channels - 1) * (in_stride or n_in) + n_in) * self._in_bytes())
+            self._fits("output", d_out, ((n_channels - 1) * (out_stride or cnt) + cnt) * np.dtype(self.out_dtype).itemsize)
         check(lib().sdr_fir_execute_batched_dev(self.h, _vp(d_in), C.c_size_t(n_in),
                                                 C.c_size_t(in_stride), C.c_size_t(n_channels),
                                                 _vp(d_out), C.c_size_t(out_stride),
@@ -249,6 +272,10 @@ class FirPlan:
     def time_dev(self, d_in, n_in, d_out, iters, in_stride=0, n_channels=1, out_stride=0,
                  stream=None):
         """average ms per kernel launch, measured with HIP events on the launch stream"""
+        cnt = self.out_count(n_in)
+        if n_channels > 0:
+            self._fits("input", d_in, ((n_channels - 1) * (in_stride or n_in) + n_in) * self._in_bytes())
+            self._fits("output", d_out, ((n_channels - 1) * (out_stride or cnt) + cnt) * np.dtype(self.out_dtype).itemsize)
         ms = C.c_float()
         check(lib().sdr_fir_time_dev(self.h, _vp(d_in), C.c_size_t(n_in), C.c_size_t(in_stride),
                                      C.c_size_t(n_channels), _vp(d_out), C.c_size_t(out_stride),

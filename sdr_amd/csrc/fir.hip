@@ -42,7 +42,9 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "sdr_internal.h"
@@ -1161,6 +1163,28 @@ __device__ __forceinline__ int i8_tile_channel(const FirGeom &g, int t)
     return g.total_tiles == g.tiles_per_ch ? 0 : t / g.tiles_per_ch;
 }
 
+// Tile hand-out.  Static: the n-th tile of a workgroup is i8_tile_index(n).  Dynamic (qctr != nullptr, a
+// grid of a multiple of eight workgroups): the workgroups of XCD x draw the tiles of that same sequence
+// -- the x-th eighth of every round, in order -- from one counter per XCD, so a compute unit that runs
+// slow (the memory channels are not equally near to all of them) takes fewer tiles instead of holding
+// the launch up; a bare persistent reader gains 3.5 % that way (tools/ubench/stream_read.hip).  Results
+// do not depend on who computes a tile.  Counters: one per 128-byte line, qctr[32 * x], and the count
+// of finished workgroups at qctr[32 * 8]; the last workgroup to finish zeroes them for the next launch.
+constexpr int kI8QueueWords = 32 * 9;
+// one lane: `count` consecutive places in this XCD's sequence (dynamic) -- returns the first
+__device__ __forceinline__ unsigned i8_draw(unsigned *qctr, unsigned count)
+{
+    return atomicAdd(&qctr[32 * (blockIdx.x & 7)], count);
+}
+// tile at place q of this XCD's sequence, or -1 past the end (G = gridDim.x, x = blockIdx.x & 7: kept in
+// scalar registers by the caller -- read where they are used, the dispatch packet is loaded again in
+// every phase, and the wait for that load also waits for whatever LDS read is in flight)
+__device__ __forceinline__ int i8_tile_at(const FirGeom &g, unsigned G, unsigned x, unsigned q)
+{
+    const unsigned G8 = G >> 3, r = q / G8;
+    const long long t = (long long)r * G + x * G8 + (q - r * G8);
+    return t < g.total_tiles ? (int)t : -1;
+}
 struct I8Tile {
     const unsigned char *vbase;   // the tile's first valid sample (inside the caller's buffer; wave-uniform)
     int lo, hi;                   // valid samples of the tile, tile-relative: [lo, hi)
@@ -1299,18 +1323,17 @@ __device__ __forceinline__ void i8_startup_fm_output(const uint32_t *__restrict_
     if (lane == 0) out[ch * g.out_stride + (m - g.out_begin)] = discriminate(a1, a0, g.scale);
 }
 
-// Finishing of tile number n of this workgroup (computed in the previous phase, outputs in ybuf[par]):
+// Finishing of tile t (computed in the previous phase, outputs in ybuf[par]):
 // finishing lane F takes outputs RH*F .. RH*F + RH-1 of the tile and, for the discriminator, their
 // successor.  A column block (128 outputs) is kI8PartSlots float4 slots, component 0's outputs in order
 // from slot 0, component 1's from slot 33.
 template <int RH, int NCB>
-__device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ outv, const float *ybuf, int par, int F, int n)
+__device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ outv, const float *ybuf, int par, int F, int t)
 {
     constexpr int TILE = 128 * NCB;
     const int o0 = RH * F, o2 = o0 + RH < TILE ? o0 + RH : TILE - 1;
     const float *pa = ybuf + par * NCB * (4 * kI8PartSlots) + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
     const float *pb = ybuf + par * NCB * (4 * kI8PartSlots) + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
-    const int t = i8_tile_index(n);
     const int ch = i8_tile_channel(g, t);
     const long long M0 = g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile;
     if (RH > 2 && g.mode == SDR_MODE_IQ) {
@@ -1349,25 +1372,56 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
 // PRE = octets (8 samples) per helper lane and tile: 256 * PRE * 8 samples cover the staged tile.
 // S8 = int8 sample pairs (SDR_IN_I8_IQ): one byte plane per component, four byte products per step
 // (every tap digit with the sample byte; weights 2^0 .. 2^24, no low-byte bias), one 16-byte load per octet.
-template <int NS, int NCB, int PRE, bool S8>
+// DYN = tiles are drawn from the per-XCD counters at qctr (see i8_draw) instead of the static order.
+template <int NS, int NCB, int PRE, bool S8, bool DYN>
 __global__ void __launch_bounds__(512, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
-                   const int plane_bytes, const float yscale, const float *__restrict__ ftaps)
+                   const int plane_bytes, const float yscale, const float *__restrict__ ftaps,
+                   unsigned *__restrict__ qctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const bool matrix = tid < 256;
     const int buf_bytes = 4 * plane_bytes;
     f32x4 *ybuf = (f32x4 *)(smem + 2 * buf_bytes);             // [tile parity][column block][kI8PartSlots]
-    // this workgroup's tiles: n_t rounds (the last one may be partial)
-    const int n_t = (g.total_tiles - i8_tile_index(0) + (int)gridDim.x - 1) / (int)gridDim.x;
-    // phases: tile t is staged in phase t, multiplied in t+1, finished in t+2; an even count, so that
-    // the helper waves' loop over their two register sets has no conditional half
-    const int n_ph = (n_t + 3) & ~1;
+    // Phases: this workgroup's n-th tile is staged in phase n, multiplied in n+1, finished in n+2; phases
+    // run in pairs, so that the helper waves' loop over their two register sets has no conditional half,
+    // and every wave ends on the same test of the same tile numbers (tile_of: -1 past the last tile).
+    // Static order: tile_of is arithmetic.  Dynamic order: the number is written to tq[n & 7] four phases
+    // ahead by matrix wave 0 (that wave has no loads in flight an atomic's return would have to queue
+    // behind), and every wave works from a snapshot of the eight entries (lane i holds tq[i & 7]) that
+    // it took at the start of the phase before -- read in the phase that uses them, the LDS round trip
+    // would sit in front of every phase's address arithmetic.  The snapshot of phase p-1 holds the tiles
+    // up to p+2, all that phase p needs; the entry written meanwhile (tile p+3) is not among them.
+    int *tq = (int *)(smem + 2 * buf_bytes + 2 * NCB * kI8PartSlots * 16 + (NS > 8 ? kI8MaxSteps * 1024 : 0));
+    unsigned q_drawn = 0;                                      // (lane 0 of wave 0) the place drawn in the previous phase
+    unsigned G = gridDim.x, xcd = blockIdx.x & 7;
+    int slot0 = i8_tile_index(0);
+    int tq_snap = 0;
+    const int n_t = (g.total_tiles - slot0 + (int)G - 1) / (int)G;   // static order: this workgroup's tiles ...
+    // ... and phases.  (Dynamic order: an upper bound, left early: hipcc schedules the loops with a trip
+    // count visibly better than the same loops without one -- 7 % on short phases.)
+    const int n_ph_s = DYN ? (g.total_tiles + 4) & ~1 : (n_t + 3) & ~1;
+    if constexpr (DYN) {
+        asm volatile("" : "+s"(G), "+s"(xcd));                 // (opaque: kept in registers, not loaded again in every phase)
+        if (tid == 0) {
+            const unsigned q0 = i8_draw(qctr, 5u);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) tq[n] = n >= 4 ? -1 : i8_tile_at(g, G, xcd, q0 + n);
+            q_drawn = q0 + 4;
+        }
+        __syncthreads();
+        tq_snap = tq[tid & 7];
+    }
+    auto tile_of = [&](int n) -> int {                         // n in p-2 .. p+2
+        if constexpr (DYN) return n < 0 ? -1 : __builtin_amdgcn_readlane(tq_snap, n & 7);
+        else return (n >= 0 && n < n_t) ? n * (int)G + slot0 : -1;
+    };
     // who finishes: 0 the matrix waves, 1 the helper waves, 2 both (one half of the tile each; see the matrix waves)
     constexpr int FIN = (NCB == 8 && PRE <= (S8 ? 6 : 4)) ? 2 : 0;
     I8Clock clk;
+    int n_ph = 0;
 
     if (matrix) {
         // four matrix waves, one per SIMD; wave w takes column blocks CBW*w .. CBW*w + CBW-1 of every tile
@@ -1389,10 +1443,21 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 if (A0_LDS && d == 0) { if (wave == 0) a0lds[ks * 64 + lane] = atab[(ks * 4) * 64 + lane]; }
                 else a[ks][d] = as_i32x4(atab[(ks * 4 + d) * 64 + lane]);
             }
+        // dynamic order: the digits are waited for here, once -- left to their first use inside the loop,
+        // the wait (s_waitcnt vmcnt(0) between two MFMAs) stays in every phase of that loop and then also
+        // waits for the acknowledgement of the stores the wave has just issued (the counted loop of the
+        // static order is peeled by hipcc, and the wait stays in its first round)
+        if constexpr (DYN) {
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+                for (int d = (A0_LDS ? 1 : 0); d < 4; ++d) asm volatile("" ::"v"(a[ks][d]));
+        }
         // 128 * (sum of the row's digits), combined over the digits exactly as the accumulators are
         // below: it undoes the -128 of the low bytes, and because the combination is the same sequence
         // of float32 operations on the negated integers, zero samples still give an exact zero
         const f32x4 bias = S8 ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, btab[lane]);
+        if (DYN && !S8) asm volatile("" ::"v"(bias));          // (waited for here, like the digits above)
         // hi plane of component j&1, this lane's group within a column block, step 0
         const int bofs = (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq + CBW * wave * (16 * g.D * 8);
         const int cb_bytes = 16 * g.D * 8;                     // between column blocks
@@ -1408,12 +1473,28 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // 0.495, 255/4 0.341 -> 0.306, 511/10 0.194 -> 0.183; wider tiles lose 5-10 % that way).
         constexpr int R = NCB / 2;
         clk.start();
-        for (int p = 0; p < n_ph; ++p) {
+        int p = 0;
+        for (; p < n_ph_s; ++p) {
+            const int t_fin = tile_of(p - 2);
+            if (DYN && !(p & 1) && p >= 2 && t_fin < 0) break; // both of this pair's tiles lie past the end
+            int tq_in = 0;
+            if constexpr (DYN) {
+                tq_in = tq[tid & 7];
+                // the tile staged four phases from now: its place was drawn a phase ago, behind that phase's
+                // stores, so the atomic's return has had a whole phase to arrive (a wave's memory operations
+                // are waited for in order: asked for at the end of the phase it was drawn in, the return
+                // would wait for the stores' acknowledgements too: +7 % on the headline)
+                if (wave == 0) {                               // (scalar arithmetic on the drawn place)
+                    const int t_new = i8_tile_at(g, G, xcd, (unsigned)__builtin_amdgcn_readfirstlane((int)q_drawn));
+                    if (lane == 0) tq[(p + 4) & 7] = t_new;
+                }
+            }
             // the tile before the last
-            if (FIN != 1 && p >= 2 && p - 2 < n_t && !(SDR_I8_ABL & 4))
-                i8_finish<(FIN == 2 ? R / 2 : R), NCB>(g, outv, (const float *)ybuf, p & 1, tid, p - 2);
+            if (FIN != 1 && t_fin >= 0 && !(SDR_I8_ABL & 4))
+                i8_finish<(FIN == 2 ? R / 2 : R), NCB>(g, outv, (const float *)ybuf, p & 1, tid, t_fin);
+            if (DYN && wave == 0 && lane == 0) q_drawn = i8_draw(qctr, 1u);
             clk.mark(2);
-            const bool work = p >= 1 && p <= n_t && !(SDR_I8_ABL & 1);
+            const bool work = tile_of(p - 1) >= 0 && !(SDR_I8_ABL & 1);
             if (work) {
                 const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs;
                 // units of (column block, step), samples requested PD units ahead (int8 samples: a unit
@@ -1487,10 +1568,12 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if constexpr (DYN) tq_snap = tq_in;
             clk.arrive();
             lds_only_barrier();
             clk.leave();
         }
+        n_ph = p;
     } else {
         // ================= helper waves: stage tile p, request tile p+2 ===========================
         const int st = tid - 256;                              // 0..255
@@ -1502,16 +1585,19 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         constexpr int LPO = S8 ? 1 : 2;                        // 16-byte loads per octet
         uint4 w0[kI8Pre][LPO], w1[kI8Pre][LPO];
         // n-th tile of this workgroup, and its descriptor kept (in scalar registers) until it is staged.
-        // Unconditional (past the end: the last tile again, unused): a skipped request would make the
+        // Unconditional (past the end: the launch's first tile, unused): a skipped request would make the
         // registers conditionally defined and hipcc would copy them right after the loads
-        auto request = [&](int n, uint4 (&w)[kI8Pre][LPO], I8Tile &tl) {
-            tl = i8_tile<S8>(g, in, i8_tile_index(n < n_t ? n : n_t - 1));
+        auto request = [&](int t, uint4 (&w)[kI8Pre][LPO], I8Tile &tl) {
+            tl = i8_tile<S8>(g, in, t < 0 ? 0 : t);
 #pragma unroll
             for (int k = 0; k < kI8Pre; ++k)
 #pragma unroll
                 for (int h = 0; h < LPO; ++h) w[k][h] = i8_fetch<S8>(tl, LPO * (256 * k + st) + h);
         };
         auto phase = [&](int p, uint4 (&w)[kI8Pre][LPO], I8Tile &tl) {
+            const int t_req = tile_of(p + 2), t_fin = tile_of(p - 2);
+            int tq_in = 0;
+            if constexpr (DYN) tq_in = tq[tid & 7];
             // (past the last tile: the last one again, into a buffer nobody reads any more -- a skipped
             // staging would leave the set's loads pending on one path into the request below, and hipcc
             // would then wait for every outstanding load, the other set's included, on all paths)
@@ -1551,17 +1637,18 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 }
             }
             clk.mark(0);
-            request(p + 2, w, tl);
+            request(t_req, w, tl);
             clk.mark(1);
-            if (FIN != 0 && p >= 2 && p - 2 < n_t && !(SDR_I8_ABL & 4))
-                i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, p - 2);
+            if (FIN != 0 && t_fin >= 0 && !(SDR_I8_ABL & 4))
+                i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin);
+            if constexpr (DYN) tq_snap = tq_in;
             clk.arrive();
             lds_only_barrier();
             clk.leave();
         };
         I8Tile tl0, tl1;
-        request(0, w0, tl0);
-        request(1, w1, tl1);
+        request(tile_of(0), w0, tl0);
+        request(tile_of(1), w1, tl1);
         if (ftaps) {
             // outputs [out_begin, store_from) of every channel: see i8_startup_fm_output; dealt over the
             // helper waves of the whole grid, done behind the first two requests (their loads are in flight meanwhile)
@@ -1572,9 +1659,20 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             }
         }
         clk.start();
-        for (int p = 0; p < n_ph; p += 2) {
+        int p = 0;
+        for (; p < n_ph_s && (!DYN || p < 2 || tile_of(p - 2) >= 0); p += 2) {
             phase(p, w0, tl0);
             phase(p + 1, w1, tl1);
+        }
+        n_ph = p;
+    }
+    // the last workgroup to get here zeroes the counters for the next launch (every draw of a workgroup
+    // precedes its own count here)
+    if (DYN && tid == 0) {
+        __threadfence();
+        if (atomicAdd(&qctr[32 * 8], 1u) == gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x < 9; ++x) atomicExch(&qctr[32 * x], 0u);
         }
     }
     clk.flush(outv, g.out_end - g.out_begin, n_ph);
@@ -1604,6 +1702,14 @@ struct sdr_fir_plan {
     bool mfma_i8 = false;   // fir_mfma_i8_kernel (byte-split Toeplitz GEMM on the int8 matrix pipe, persistent)
     uint4 *d_atab8 = nullptr;   // its A-operand table (tap digits)
     uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave
+    // tile counters of its dynamic hand-out (i8_draw): one block of kI8QueueWords per stream that launches
+    // the plan, so that launches enqueued on several streams never share one (launches of one stream run
+    // one after the other; the last workgroup of each leaves the block zeroed)
+    unsigned *d_i8q = nullptr;
+    static constexpr int kQueueStreams = 8;
+    mutable std::mutex q_mu;
+    mutable hipStream_t q_stream[kQueueStreams] = {};
+    mutable int q_used = 0;
     float *d_ftaps = nullptr;   // float32 taps (Q11 folded) for i8_startup_fm_output (discriminator plans)
     int plane_bytes = 0;
     float yscale = 1.f;         // its output scale 2^-(F+11)
@@ -1687,17 +1793,46 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
     *what = "fir kernel launch";
     if (p->mfma_i8) {
         const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);
-#define SDR_I8Q(NS, CB, PRE, S8)                                                                 \
-    do {                                                                                         \
-        SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE, S8>));                                       \
-        fir_mfma_i8_kernel<NS, CB, PRE, S8><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
-                                                                  p->plane_bytes, p->yscale,                 \
-                                                                  g.store_from > g.out_begin ? p->d_ftaps : nullptr); \
-    } while (0)
-#define SDR_I8P(NS, CB, PRE) do { if (p->input == SDR_IN_I8_IQ) SDR_I8Q(NS, CB, PRE, true); else SDR_I8Q(NS, CB, PRE, false); } while (0)
         // the helper lanes hold a whole staged tile in registers: 4, 6 or 8 octets each (plan creation
         // refuses tiles beyond 256 * 8 octets)
         const int pre = ((p->s_gran + 1) / 2 + 255) / 256;
+        // Dynamic tile hand-out for long launches (128 tiles per workgroup and more: the static order's
+        // imbalance grows with the launch, 0 / 2 / 5 / 9 % at 2^27 / 2^28 / 2^29 / 2^30 samples of the
+        // headline shape) of tiles of 1024 outputs and more than four octets per helper lane (D >= 8;
+        // shorter phases do not hide the queue's upkeep) with windows of up to four steps (256 samples:
+        // the shapes the sample stream bounds.  Where the matrix pipe is the bound every compute unit
+        // takes the same time per tile and the queue only costs: +2 % at 511 taps / 10, -1.5 .. +3 % at
+        // 200 / 10 from box to box), on a grid of whole XCD groups.  Launches under
+        // stream capture (a replayed graph may run on any stream, beside anything) and streams beyond
+        // the plan's eight counter blocks keep the static order.
+        unsigned *qctr = nullptr;
+        static const bool static_order = std::getenv("SDRHIP_STATIC_TILES") != nullptr;   // A/B measurements
+        if (p->d_i8q && !static_order && p->R == 4 && pre > 4 && p->ngran <= 4 && (nb & 7) == 0 && g.total_tiles >= 128LL * nb) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+            if (cs == hipStreamCaptureStatusNone) {
+                std::lock_guard<std::mutex> lk(p->q_mu);
+                int slot = -1;
+                for (int i = 0; i < p->q_used; ++i)
+                    if (p->q_stream[i] == st) slot = i;
+                if (slot < 0 && p->q_used < sdr_fir_plan::kQueueStreams) { slot = p->q_used++; p->q_stream[slot] = st; }
+                if (slot >= 0) qctr = p->d_i8q + (size_t)slot * kI8QueueWords;
+            }
+        }
+#define SDR_I8K(NS, CB, PRE, S8, DYN)                                                            \
+    do {                                                                                         \
+        SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN>));                                  \
+        fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
+                                                                  p->plane_bytes, p->yscale,                 \
+                                                                  g.store_from > g.out_begin ? p->d_ftaps : nullptr, qctr); \
+    } while (0)
+        // (the dynamic order is instantiated where the rule above can choose it)
+#define SDR_I8Q(NS, CB, PRE, S8)                                                                 \
+    do {                                                                                         \
+        if constexpr (CB == 8 && PRE > 4 && NS == 4) { if (qctr) { SDR_I8K(NS, CB, PRE, S8, true); break; } } \
+        SDR_I8K(NS, CB, PRE, S8, false);                                                         \
+    } while (0)
+#define SDR_I8P(NS, CB, PRE) do { if (p->input == SDR_IN_I8_IQ) SDR_I8Q(NS, CB, PRE, true); else SDR_I8Q(NS, CB, PRE, false); } while (0)
 #define SDR_I8(NS, CB) do { if (pre <= 4 && CB == 8) SDR_I8P(NS, 8, 4); else if (pre <= 6) SDR_I8P(NS, CB, 6); else SDR_I8P(NS, CB, 8); } while (0)
         // 512-output tiles are taken for D >= 16 only (the larger tile then exceeds the LDS or the helper
         // lanes' registers): their windows have more than four steps and their tiles more than four
@@ -1709,6 +1844,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
 #undef SDR_I8
 #undef SDR_I8P
 #undef SDR_I8Q
+#undef SDR_I8K
         return hipGetLastError();
     }
     if (p->ksplit) {
@@ -1917,7 +2053,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const int nks = (Wn + 63) / 64, steps = (nks + 3) / 4;
         const long long s_big = 16LL * d->decim * 63 + 256LL * steps;
         const bool big = s_big <= 8 * 256 * 8 &&
-                         2 * 4 * (roundup((int)s_big, 256) + 240) + 2 * 8 * kI8PartSlots * 16 + (steps > 2 ? 12 * 1024 : 0) <= 160 * 1024;
+                         2 * 4 * (roundup((int)s_big, 256) + 240) + 2 * 8 * kI8PartSlots * 16 + (steps > 2 ? 12 * 1024 : 0) + 64 <= 160 * 1024;
         const double tile_us = (s8 ? 0.78 + 0.06 * nks + 0.045 * d->decim : 0.7 + 0.112 * nks + 0.085 * d->decim) * (big ? 1.0 : 0.55);
         const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
         const double t_hbm = ((s8 ? 2.0 : 4.0) + 4.0 / d->decim) * 268435456.0 / 5.4e12 * 1e3;
@@ -1982,7 +2118,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             }
             const int plane = base + best_skew;
             // two tile buffers + two tiles of outputs + the lowest tap digits of a 12-step window
-            const int lds = 2 * 4 * plane + 2 * cand * kI8PartSlots * 16 + (ns > 2 ? kI8MaxSteps * 1024 : 0);
+            const int lds = 2 * 4 * plane + 2 * cand * kI8PartSlots * 16 + (ns > 2 ? kI8MaxSteps * 1024 : 0) + 64;   // + the tile queue
             // the helper lanes hold the staged tile in registers, at most 8 octets of samples each
             const bool wide = (s_tile / 4 + 1) / 2 > 256 * 8;
             if ((lds > 160 * 1024 || wide) && cand > 4) continue;
@@ -2216,6 +2352,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
     if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_atab8, at8.size() * sizeof(uint4));
     if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_atab8, at8.data(), at8.size() * sizeof(uint4), hipMemcpyHostToDevice);
+    if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_i8q, sdr_fir_plan::kQueueStreams * kI8QueueWords * sizeof(unsigned));
+    if (e == hipSuccess && p->mfma_i8) e = hipMemset(p->d_i8q, 0, sdr_fir_plan::kQueueStreams * kI8QueueWords * sizeof(unsigned));
     if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_btab8, bt8.size() * sizeof(uint4));
     if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_btab8, bt8.data(), bt8.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess && p->mfma_i8 && p->mode == SDR_MODE_FM) e = hipMalloc((void **)&p->d_ftaps, hf.size() * sizeof(float));
@@ -2244,6 +2382,7 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (p->tiny) (void)sdr_fir_plan_destroy(p->tiny);
     if (p->d_atab8) (void)hipFree(p->d_atab8);
     if (p->d_btab8) (void)hipFree(p->d_btab8);
+    if (p->d_i8q) (void)hipFree(p->d_i8q);
     if (p->d_ftaps) (void)hipFree(p->d_ftaps);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);

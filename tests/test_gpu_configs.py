@@ -157,6 +157,61 @@ def test_cfg5_full_size(sdr, oracle):
     assert np.isfinite(d_x9.to_numpy(np.float32, n9)).all()
 
 
+def test_headline_long_launch_dynamic_tile_order(sdr, oracle):
+    """A launch long enough for the int8 matrix kernel's dynamic tile hand-out (128 tiles per workgroup
+    and more; 64 taps / 10 on 2^29 samples): which workgroup computes a tile must not show in the
+    results.  The whole stream is launched on two HIP streams at once (each has its own tile counters),
+    both outputs must be identical bit for bit, equal three short time shards (static order) on their
+    ranges, match the oracle on the stream's head, and leave the sentinels behind the outputs alone.
+    A second launch on the same stream finds the counters zeroed by the first."""
+    hip = C.CDLL("libamdhip64.so")
+    n, D, T = (1 << 29) + 12345, 10, 64
+    h = sdr.create_fir_filter(T, 0.1, "hann")
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM)
+    assert plan.info()["kernel"] == "mfma_i8"
+    cnt = plan.out_count(n)
+    d_in = sdr.DevBuf(n * 4)
+    sdr.capi.synth_fm_i16_dev(d_in, n, fs=20e6, ftone=1000.0, dev=5000.0, amp=2000.0, noise_lsb=3, seed=11)
+    SENT = np.float32(-777.5)
+    streams = [C.c_void_p(), C.c_void_p()]
+    for s_ in streams:
+        assert hip.hipStreamCreate(C.byref(s_)) == 0
+    outs = [sdr.DevBuf((cnt + 8) * 4) for _ in range(3)]
+    for o in outs:
+        fill(sdr, o, SENT, 8, offset_bytes=cnt * 4)
+    try:
+        assert plan.execute_dev(d_in, n, outs[0], cnt, stream=streams[0].value) == cnt
+        assert plan.execute_dev(d_in, n, outs[1], cnt, stream=streams[1].value) == cnt
+        assert plan.execute_dev(d_in, n, outs[2], cnt, stream=streams[0].value) == cnt     # same stream again
+        sdr.sync()
+    finally:
+        for s_ in streams:
+            hip.hipStreamDestroy(s_)
+    a = outs[0].to_numpy(np.float32, cnt + 8)
+    assert (a[cnt:] == SENT).all()
+    for o in outs[1:]:
+        b = o.to_numpy(np.float32, cnt + 8)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        del b
+    # three short shards of the same stream (few tiles per workgroup: the static order)
+    for ob in (0, cnt // 2 - 7, cnt - 300_000):
+        oe = ob + 300_000
+        lo = max(0, ob * D - (T - 1))
+        hi = min(n, (oe + 1) * D + 1)
+        d_out = sdr.DevBuf((oe - ob) * 4)
+        plan.execute_range_dev(d_in.at(4 * lo), lo, hi - lo, n, ob, oe, d_out)
+        sdr.sync()
+        assert np.array_equal(d_out.to_numpy(np.float32, oe - ob), a[ob:oe]), ob
+    # the oracle on the head of the stream
+    m = 1 << 18
+    iq = d_in.to_numpy(np.int16, 2 * m)
+    want = oracle.chain_i16(iq, D, h, oracle.MODE_FM, 1.0 / TWO_PI)
+    s0 = T // D + 2                                     # the start-up transient: ill-conditioned angles (sdr_hip.h)
+    err = np.abs(a[s0: want.size - 1].astype(np.float64) - want[s0:-1])
+    err = np.minimum(err, 1.0 - err)
+    assert err.max() <= 1e-5 * 0.5, err.max()
+
+
 @pytest.mark.parametrize("pipe", [1, 5])
 def test_two_ranks_time_split_through_hip(sdr, oracle, pipe):
     """shard.plan_time_shards with the HIP kernels as the per-rank compute: two 'ranks' run back to

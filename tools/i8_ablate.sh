@@ -6,7 +6,7 @@ set -eu
 cd "$(dirname "$0")/.."
 mkdir -p tools/exp
 VARS="${VARS:-8 16 32 48 6 22 54}"
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Isdr_amd/csrc"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Isdr_amd/csrc -mllvm -amdgpu-atomic-optimizer-strategy=None"
 O="sdr_amd/build/lib.o sdr_amd/build/fft.o sdr_amd/build/fft_wave.o sdr_amd/build/stream.o sdr_amd/build/apt.o"
 case "${1:-build}" in
 build)

@@ -12,7 +12,7 @@ sdr_amd.init(0)
 n = 1 << log2n
 d_in = sdr_amd.DevBuf(n * 4 + 64)
 sdr_amd.capi.synth_fm_i16_dev(d_in, n, fs=20e6, noise_lsb=8)
-d_out = sdr_amd.DevBuf(n + 64)
+d_out = sdr_amd.DevBuf((n // D + 64) * 8)              # room for complex outputs at any D
 h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
 p = sdr_amd.FirPlan(h, D, mode=mode, outputs_per_lane=R, threads=NT, pipeline=pipe)
 p.time_dev(d_in, n, d_out, 40)          # clocks ramp over the first ~20 launches after idle

@@ -147,6 +147,115 @@ __global__ void __launch_bounds__(256) read_tiles_seq(const uint4 *in, float *ou
     }
 }
 
+// 40 KB tile per workgroup, XCD-contiguous, non-temporal stores.  PAIR: a lane reads the adjacent pieces
+// 2*i and 2*i+1 with two instructions (each instruction then covers a 2 KB span at a 32-byte lane stride,
+// as the int8 FIR kernel's helper lanes do); otherwise every instruction reads 1 KB of consecutive bytes.
+template <bool PAIR>
+__global__ void __launch_bounds__(256) read_tiles_pair(const uint4 *in, float *out, size_t n16)
+{
+    const size_t tile = (size_t)(blockIdx.x & 7) * (gridDim.x / 8) + (blockIdx.x >> 3);
+    const size_t base = tile * 2560;
+    unsigned acc = 0;
+    uint4 a[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+        a[k] = PAIR ? in[base + 2 * ((k >> 1) * 256 + threadIdx.x) + (k & 1)] : in[base + k * 256 + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w;
+    float *p = out + (tile * 512 + threadIdx.x * 2) * 2;
+    __builtin_nontemporal_store(__uint_as_float(acc), p);
+    __builtin_nontemporal_store(1.f, p + 1);
+    __builtin_nontemporal_store(2.f, p + 2);
+    __builtin_nontemporal_store(3.f, p + 3);
+}
+
+// in-flight depth: persistent workgroups (one per CU, 256 loader lanes, as the int8 FIR kernel's helper
+// waves) that keep DEPTH 40 KB tiles in flight: tile t+DEPTH is requested when tile t has been consumed
+template <int DEPTH>
+__global__ void __launch_bounds__(256, 1) read_persistent(const uint4 *in, float *out, size_t n16)
+{
+    const int G = gridDim.x, b = blockIdx.x;
+    const size_t slot = (size_t)(b & 7) * (G >> 3) + (b >> 3);
+    const size_t n_tiles = n16 / 2560;
+    const int n_t = (int)((n_tiles - slot + G - 1) / G);
+    uint4 a[DEPTH][10];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const size_t tile = (size_t)(d < n_t ? d : n_t - 1) * G + slot;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) a[d][k] = in[tile * 2560 + k * 256 + threadIdx.x];
+    }
+    for (int t = 0; t < n_t; t += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const size_t tile = (size_t)(t + d) * G + slot;
+            unsigned acc = 0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) acc ^= a[d][k].x ^ a[d][k].y ^ a[d][k].z ^ a[d][k].w;
+            const int nx = t + d + DEPTH < n_t ? t + d + DEPTH : n_t - 1;
+            const size_t tn = (size_t)nx * G + slot;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[d][k] = in[tn * 2560 + k * 256 + threadIdx.x];
+            if (t + d < n_t) {
+                float *p = out + (tile * 512 + threadIdx.x * 2) * 2;
+                __builtin_nontemporal_store(__uint_as_float(acc), p);
+                __builtin_nontemporal_store(1.f, p + 1);
+                __builtin_nontemporal_store(2.f, p + 2);
+                __builtin_nontemporal_store(3.f, p + 3);
+            }
+        }
+    }
+}
+
+// the same persistent reader, two tiles in flight, but tiles handed out by an atomic counter instead of
+// a static round-robin: MODE 0 = one global counter, MODE 1 = one counter per XCD over its contiguous eighth
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) read_persistent_dyn(const uint4 *in, float *out, size_t n16, unsigned *ctr)
+{
+    __shared__ unsigned nxt[4];
+    const int G = gridDim.x, b = blockIdx.x, x = b & 7;
+    const unsigned n_tiles = (unsigned)(n16 / 2560) & ~7u;
+    const unsigned per_x = n_tiles / 8;
+    auto grab = [&]() -> unsigned {            // all lanes return the same tile (or >= n_tiles)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned v = atomicAdd(&ctr[MODE ? 32 * x : 0], 1u);
+            nxt[0] = MODE ? (v < per_x ? x * per_x + v : n_tiles) : v;
+        }
+        __syncthreads();
+        return nxt[0];
+    };
+    uint4 a[2][10];
+    unsigned tl[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        tl[d] = grab();
+        const size_t tile = tl[d] < n_tiles ? tl[d] : 0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) a[d][k] = in[tile * 2560 + k * 256 + threadIdx.x];
+    }
+    while (tl[0] < n_tiles || tl[1] < n_tiles) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const unsigned tile = tl[d];
+            unsigned acc = 0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) acc ^= a[d][k].x ^ a[d][k].y ^ a[d][k].z ^ a[d][k].w;
+            tl[d] = grab();
+            const size_t tn = tl[d] < n_tiles ? tl[d] : 0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[d][k] = in[tn * 2560 + k * 256 + threadIdx.x];
+            if (tile < n_tiles) {
+                float *p = out + ((size_t)tile * 512 + threadIdx.x * 2) * 2;
+                __builtin_nontemporal_store(__uint_as_float(acc), p);
+                __builtin_nontemporal_store(1.f, p + 1);
+                __builtin_nontemporal_store(2.f, p + 2);
+                __builtin_nontemporal_store(3.f, p + 3);
+            }
+        }
+    }
+}
+
 int main()
 {
     const size_t n = (size_t)1 << 30;          // samples, 4 B each
@@ -155,10 +264,11 @@ int main()
     hipMalloc(&in, n * 4 + 65536);
     hipMalloc(&out, n / 10 * 4 + (1 << 22));
     hipMemset(in, 1, n * 4);
+    unsigned *ctr; hipMalloc(&ctr, 4096);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double bytes = 4.4 * (double)n;
-    for (int variant = 9; variant < 22; ++variant) {
-        if (variant >= 11 && variant <= 15) continue;
+    for (int variant = 9; variant < 30; ++variant) {
+        if (variant >= 10 && variant <= 21) continue;
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(e0);
@@ -184,13 +294,21 @@ int main()
                 if (variant == 19) read_tiles_store<6><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
                 if (variant == 20) read_tiles_store<7><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
                 if (variant == 21) read_tiles_store<8><<<(unsigned)(n16 / 1280) & ~7u, 256>>>(in, out, n16);
+                if (variant == 22) read_tiles_pair<false><<<(unsigned)(n16 / 2560) & ~7u, 256>>>(in, out, n16);
+                if (variant == 23) read_tiles_pair<true><<<(unsigned)(n16 / 2560) & ~7u, 256>>>(in, out, n16);
+                if (variant == 24) read_persistent<1><<<256, 256>>>(in, out, n16);
+                if (variant == 25) read_persistent<2><<<256, 256>>>(in, out, n16);
+                if (variant == 26) read_persistent<3><<<256, 256>>>(in, out, n16);
+                if (variant == 27) read_persistent<4><<<256, 256>>>(in, out, n16);
+                if (variant == 28) { hipMemsetAsync(ctr, 0, 4096, 0); read_persistent_dyn<0><<<256, 256>>>(in, out, n16, ctr); }
+                if (variant == 29) { hipMemsetAsync(ctr, 0, 4096, 0); read_persistent_dyn<1><<<256, 256>>>(in, out, n16, ctr); }
                 if (variant == 8) read_tiles_v<10, true, true><<<(unsigned)(n16 / 2560) & ~7u, 256>>>(in, out, n16);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
             if (rep && ms < best) best = ms;
         }
-        const char *nm[22] = {"grid-stride 8 wg/CU", "grid-stride 32 wg/CU", "20 KB tile per wg, vector loads", "20 KB tile per wg, LDS-DMA", "40 KB tile", "20 KB tile, nontemporal", "20 KB tile, XCD-contiguous", "80 KB tile", "40 KB nontemporal XCD-contiguous", "20 KB XCD-contiguous, NO stores", "20 KB XCD-contiguous, nontemporal stores", "20 KB XCD-contiguous, dwordx4 stores from 2 waves", "2 tiles in sequence per wg", "4 tiles in sequence per wg", "8 tiles in sequence per wg", "4 tiles in sequence, nontemporal stores", "stores that stay in L2 (same 2 KB per XCD)", "stores to a permuted tile order", "every 8th tile stores 16 KB", "stores sc0 sc1", "stores nt sc0 sc1", "stores sc1"};
+        const char *nm[30] = {"grid-stride 8 wg/CU", "grid-stride 32 wg/CU", "20 KB tile per wg, vector loads", "20 KB tile per wg, LDS-DMA", "40 KB tile", "20 KB tile, nontemporal", "20 KB tile, XCD-contiguous", "80 KB tile", "40 KB nontemporal XCD-contiguous", "20 KB XCD-contiguous, NO stores", "20 KB XCD-contiguous, nontemporal stores", "20 KB XCD-contiguous, dwordx4 stores from 2 waves", "2 tiles in sequence per wg", "4 tiles in sequence per wg", "8 tiles in sequence per wg", "4 tiles in sequence, nontemporal stores", "stores that stay in L2 (same 2 KB per XCD)", "stores to a permuted tile order", "every 8th tile stores 16 KB", "stores sc0 sc1", "stores nt sc0 sc1", "stores sc1", "40 KB tile, 1 KB per load instruction", "40 KB tile, adjacent pieces per lane (32 B lane stride)", "persistent, 1 x 40 KB in flight per CU", "persistent, 2 x 40 KB in flight per CU", "persistent, 3 x 40 KB in flight per CU", "persistent, 4 x 40 KB in flight per CU", "persistent, tiles from one atomic counter", "persistent, tiles from a counter per XCD"};
         printf("%-34s %.4f ms  %.0f GB/s (4.4 B/sample)\n", nm[variant], best, bytes / best / 1e6);
     }
     return 0;

@@ -26,7 +26,10 @@
  *     (SDR_EINVAL otherwise).  Plans are immutable after creation except for the staging /
  *     scratch buffers of the *_host entry points and of FFT frames longer than 4096 points:
  *     those calls are one at a time per plan; *_dev calls of one plan may be enqueued on several
- *     streams.  The last-error text is per thread.
+ *     streams (the int8 matrix kernel keeps one block of tile counters per stream that launches a
+ *     plan, eight per plan; further streams, and launches under HIP stream capture, run with the
+ *     static tile order -- same results, a few per cent slower on long launches).  The last-error
+ *     text is per thread.
  */
 #ifndef SDR_HIP_H_
 #define SDR_HIP_H_

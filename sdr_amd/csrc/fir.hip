@@ -1163,8 +1163,8 @@ __device__ __forceinline__ int i8_tile_channel(const FirGeom &g, int t)
     return g.total_tiles == g.tiles_per_ch ? 0 : t / g.tiles_per_ch;
 }
 
-// Tile hand-out.  Static: the n-th tile of a workgroup is i8_tile_index(n).  Dynamic (qctr != nullptr, a
-// grid of a multiple of eight workgroups): the workgroups of XCD x draw the tiles of that same sequence
+// Tile hand-out.  Static: the n-th tile of a workgroup is i8_tile_index(n).  Dynamic (the DYN
+// instantiations, on a grid of a multiple of eight workgroups): the workgroups of XCD x draw the tiles of that same sequence
 // -- the x-th eighth of every round, in order -- from one counter per XCD, so a compute unit that runs
 // slow (the memory channels are not equally near to all of them) takes fewer tiles instead of holding
 // the launch up; a bare persistent reader gains 3.5 % that way (tools/ubench/stream_read.hip).  Results
@@ -1185,6 +1185,7 @@ __device__ __forceinline__ int i8_tile_at(const FirGeom &g, unsigned G, unsigned
     const long long t = (long long)r * G + x * G8 + (q - r * G8);
     return t < g.total_tiles ? (int)t : -1;
 }
+
 struct I8Tile {
     const unsigned char *vbase;   // the tile's first valid sample (inside the caller's buffer; wave-uniform)
     int lo, hi;                   // valid samples of the tile, tile-relative: [lo, hi)

@@ -1803,12 +1803,14 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         // shorter phases do not hide the queue's upkeep) with windows of up to four steps (256 samples:
         // the shapes the sample stream bounds.  Where the matrix pipe is the bound every compute unit
         // takes the same time per tile and the queue only costs: +2 % at 511 taps / 10, -1.5 .. +3 % at
-        // 200 / 10 from box to box), on a grid of whole XCD groups.  Launches under
+        // 200 / 10 from box to box; int8 sample pairs, half the bytes per tile: +-1 %), on a grid of whole
+        // XCD groups.  int16 shapes inside the rule, 2^30 samples, same box: 64/8 -8 %, 96/9 -10 %, 64/10
+        // -9 %, 100/10 -9 %, 64/11 -6 %, 64/12 -7 %, 40/14 -5 %, 30/15 0 %.  Launches under
         // stream capture (a replayed graph may run on any stream, beside anything) and streams beyond
         // the plan's eight counter blocks keep the static order.
         unsigned *qctr = nullptr;
         static const bool static_order = std::getenv("SDRHIP_STATIC_TILES") != nullptr;   // A/B measurements
-        if (p->d_i8q && !static_order && p->R == 4 && pre > 4 && p->ngran <= 4 && (nb & 7) == 0 && g.total_tiles >= 128LL * nb) {
+        if (p->d_i8q && !static_order && p->R == 4 && pre > 4 && p->ngran <= 4 && p->input != SDR_IN_I8_IQ && (nb & 7) == 0 && g.total_tiles >= 128LL * nb) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
             if (cs == hipStreamCaptureStatusNone) {
@@ -1830,7 +1832,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         // (the dynamic order is instantiated where the rule above can choose it)
 #define SDR_I8Q(NS, CB, PRE, S8)                                                                 \
     do {                                                                                         \
-        if constexpr (CB == 8 && PRE > 4 && NS == 4) { if (qctr) { SDR_I8K(NS, CB, PRE, S8, true); break; } } \
+        if constexpr (CB == 8 && PRE > 4 && NS == 4 && !S8) { if (qctr) { SDR_I8K(NS, CB, PRE, S8, true); break; } } \
         SDR_I8K(NS, CB, PRE, S8, false);                                                         \
     } while (0)
 #define SDR_I8P(NS, CB, PRE) do { if (p->input == SDR_IN_I8_IQ) SDR_I8Q(NS, CB, PRE, true); else SDR_I8Q(NS, CB, PRE, false); } while (0)

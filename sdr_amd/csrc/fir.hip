@@ -1281,55 +1281,136 @@ __device__ __forceinline__ void i8_split4(uint4 w, uint32_t &il, uint32_t &ih, u
     qh = __builtin_amdgcn_perm(c23, c01, 0x07060302u);
 }
 
+// One filter output y[m] with float32 taps, computed by a whole wave (every argument wave-uniform, all
+// 64 lanes active): lane l takes taps l, l + 64, ..., the partial sums meet in a butterfly.  One fixed
+// summation order per output, so the value depends neither on the tile nor on the shard that asks.
+// This is the arithmetic of the vector-unit kernels (float32 taps, Q11 / Q7 folded in), and what
+// fir_mfma_i8_kernel falls back to for the few outputs its fixed-point taps cannot decide (below).
+// src = sample 0 of the channel; samples outside [lo_valid, hi_valid) read as zero.
+struct I8Chan {
+    const void *src;
+    const float *taps;
+    long long lo_valid, hi_valid;
+    int D, T, swap_iq;
+};
+
+template <bool S8>
+__device__ __forceinline__ float2 i8_y_f32(const I8Chan &c, long long m, int lane)
+{
+    // one sample as (I, Q) floats: an int16 pair (either order) or an int8 pair
+    auto sample = [&](long long s) {
+        if constexpr (S8) {
+            const unsigned w = ((const unsigned short *)c.src)[s];
+            return make_float2((float)(signed char)(w & 255u), (float)(signed char)(w >> 8));
+        } else {
+            const uint32_t w = ((const uint32_t *)c.src)[s];
+            return c.swap_iq ? make_float2(hi16(w), lo16(w)) : make_float2(lo16(w), hi16(w));
+        }
+    };
+    float2 a = make_float2(0.f, 0.f);
+    const long long n0 = m * c.D;
+    for (int k = lane; k < c.T; k += 64) {
+        const float h = c.taps[k];
+        const long long s = n0 - k;
+        if (s >= c.lo_valid && s < c.hi_valid) {
+            const float2 x = sample(s);
+            a.x = __fmaf_rn(h, x.x, a.x);
+            a.y = __fmaf_rn(h, x.y, a.y);
+        }
+    }
+    return wave_sum(a);
+}
+
+template <bool S8>
+__device__ __forceinline__ I8Chan i8_chan(const uint32_t *__restrict__ in, const float *__restrict__ taps, const FirGeom &g, long long ch)
+{
+    I8Chan c;
+    c.src = (const unsigned char *)in + (S8 ? 2 : 4) * (ch * g.in_stride);
+    c.taps = taps;
+    c.lo_valid = g.lo_valid; c.hi_valid = g.hi_valid;
+    c.D = g.D; c.T = g.T; c.swap_iq = g.swap_iq;
+    return c;
+}
+
 // The discriminator outputs of a stream's start-up transient, computed with float32 taps by the
-// finishing waves of fir_mfma_i8_kernel while the pipeline fills (they have nothing to finish in
+// helper waves of fir_mfma_i8_kernel while the pipeline fills (they have nothing to finish in
 // its first two phases).  There |y| is small and the taps below the matrix kernel's fixed-point
 // resolution (2^-31 of the largest tap: the numerically-zero taps of a windowed sinc) decide the
 // angle of an output whose other y is exactly zero, which the reference reports as 0 or +-pi by
-// the signs of its zeros.  One wave per output: the lanes share the taps of y[m] and y[m+1],
-// wave-reduce, lane 0 applies the discriminator.  A few dozen outputs per stream start.
+// the signs of its zeros.  One wave per output.  A few dozen outputs per stream start.
 template <bool S8>
 __device__ __forceinline__ void i8_startup_fm_output(const uint32_t *__restrict__ in, float *__restrict__ out,
                                                      const float *__restrict__ taps, const FirGeom &g,
                                                      long long m, long long ch, int lane)
 {
-    // one sample as (I, Q) floats: an int16 pair (either order) or an int8 pair
-    auto sample = [&](long long s) {
-        if constexpr (S8) {
-            const unsigned w = ((const unsigned short *)in)[ch * g.in_stride + s];
-            return make_float2((float)(signed char)(w & 255u), (float)(signed char)(w >> 8));
-        } else {
-            const uint32_t w = in[ch * g.in_stride + s];
-            return g.swap_iq ? make_float2(hi16(w), lo16(w)) : make_float2(lo16(w), hi16(w));
-        }
-    };
-    float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
-    const long long n0 = m * g.D, n1 = n0 + g.D;
-    for (int k = lane; k < g.T; k += 64) {
-        const float h = taps[k];
-        const long long s0 = n0 - k, s1 = n1 - k;
-        if (s0 >= g.lo_valid && s0 < g.hi_valid) {
-            const float2 x = sample(s0);
-            a0.x = __fmaf_rn(h, x.x, a0.x);
-            a0.y = __fmaf_rn(h, x.y, a0.y);
-        }
-        if (s1 >= g.lo_valid && s1 < g.hi_valid) {
-            const float2 x = sample(s1);
-            a1.x = __fmaf_rn(h, x.x, a1.x);
-            a1.y = __fmaf_rn(h, x.y, a1.y);
+    const I8Chan c = i8_chan<S8>(in, taps, g, ch);
+    const float2 a0 = i8_y_f32<S8>(c, m, lane);
+    const float2 a1 = i8_y_f32<S8>(c, m + 1, lane);
+    if (lane == 0) out[ch * g.out_stride + (m - g.out_begin)] = discriminate(a1, a0, g.scale);
+}
+
+// Mid-stream twin of the start-up case: after a run of >= T zero samples the first output whose window
+// meets a non-zero sample only through taps below the fixed-point resolution is an exact 0 here and a
+// tiny vector in the reference -- and the discriminator reports the ANGLE of that vector (and, one
+// output earlier, 0 or +-pi by its signs).  Every y that came out of the matrix pipe as an exact zero
+// and feeds a stored discriminator output is therefore looked at again: if the samples under the wave's
+// outputs are not all zero, the flagged y are recomputed with float32 taps (i8_y_f32), exactly the
+// value the start-up path and the vector-unit kernels give.  An all-zero window gives +0 either way, so
+// long runs of silence cost one scan of their samples (L2 hits: the tile was staged two phases ago)
+// and no recomputation.  Lane F of the wave holds y[m0 + r], r < RH (m0 = the wave's first output +
+// RH*F) and their successor y[m0 + RH] (slot RH).  Stored outputs: store_from <= j < out_end.
+// A real function, not inlined: it runs once in a blue moon, and inlined its registers (and the scalar
+// registers of its loops) crowd the matrix waves' tap digits -- 75 scalar spills in the headline kernel.
+template <int RH> struct I8Ys { float2 y[RH + 1]; };
+
+template <int RH, bool S8>
+__device__ __noinline__ I8Ys<RH> i8_zero_fix(I8Chan c, long long m0, long long store_from, long long out_end, I8Ys<RH> v)
+{
+    const int lane = threadIdx.x & 63;
+    bool flag[RH + 1];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r <= RH; ++r) {
+        // d[j] = angle(y[j+1] conj y[j]): slot r serves d[m0 + r] (r < RH) and d[m0 + r - 1] (r > 0)
+        const long long j = m0 + r;
+        const bool used = (r < RH && j >= store_from && j < out_end) || (r > 0 && j - 1 >= store_from && j - 1 < out_end);
+        flag[r] = used && v.y[r].x == 0.f && v.y[r].y == 0.f;
+        any |= flag[r];
+    }
+    if (__ballot(any) == 0ULL) return v;
+    // the samples under all of the wave's outputs: [D*m_first - (T-1), D*(m_first + 64*RH)], valid part
+    const long long m_first = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m0 >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)m0));
+    long long s_lo = m_first * c.D - (c.T - 1), s_hi = (m_first + 64 * RH) * c.D + 1;
+    s_lo = s_lo < c.lo_valid ? c.lo_valid : s_lo;
+    s_hi = s_hi > c.hi_valid ? c.hi_valid : s_hi;
+    unsigned seen = 0u;
+    if constexpr (S8) {
+        for (long long s = s_lo + lane; s < s_hi; s += 64) seen |= ((const unsigned short *)c.src)[s];
+    } else {
+        for (long long s = s_lo + lane; s < s_hi; s += 64) seen |= ((const uint32_t *)c.src)[s];
+    }
+    if (__ballot(seen != 0u) == 0ULL) return v;
+#pragma unroll
+    for (int r = 0; r <= RH; ++r) {
+        unsigned long long todo = __ballot(flag[r]);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float2 yv = i8_y_f32<S8>(c, m_first + (long long)RH * l + r, lane);
+            if (lane == l) v.y[r] = yv;
         }
     }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == 0) out[ch * g.out_stride + (m - g.out_begin)] = discriminate(a1, a0, g.scale);
+    return v;
 }
 
 // Finishing of tile t (computed in the previous phase, outputs in ybuf[par]):
 // finishing lane F takes outputs RH*F .. RH*F + RH-1 of the tile and, for the discriminator, their
 // successor.  A column block (128 outputs) is kI8PartSlots float4 slots, component 0's outputs in order
 // from slot 0, component 1's from slot 33.
-template <int RH, int NCB>
-__device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ outv, const float *ybuf, int par, int F, int t)
+template <int RH, int NCB, bool S8>
+__device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ outv, const float *ybuf, int par, int F, int t,
+                                          const uint32_t *__restrict__ in, const float *__restrict__ ftaps)
 {
     constexpr int TILE = 128 * NCB;
     const int o0 = RH * F, o2 = o0 + RH < TILE ? o0 + RH : TILE - 1;
@@ -1365,6 +1446,24 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
         y[0] = make_float2(pa[0], pa[4 * 33]);
     }
     ynext = make_float2(pb[0], pb[4 * 33]);
+    if (g.mode == SDR_MODE_FM) {
+        // an exact zero among the y this lane's outputs read: see i8_zero_fix (rare: one compare per lane)
+        float mn = fmaxf(fabsf(ynext.x), fabsf(ynext.y));
+#pragma unroll
+        for (int r = 0; r < RH; ++r) mn = fminf(mn, fmaxf(fabsf(y[r].x), fabsf(y[r].y)));
+        if (__builtin_expect(__ballot(mn == 0.f) != 0ULL, 0)) {
+            const long long tile_end = M0 + g.per_tile;
+            I8Ys<RH> v;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) v.y[r] = y[r];
+            v.y[RH] = ynext;
+            v = i8_zero_fix<RH, S8>(i8_chan<S8>(in, ftaps, g, ch), M0 + (long long)o0, g.store_from,
+                                    tile_end < g.out_end ? tile_end : g.out_end, v);
+#pragma unroll
+            for (int r = 0; r < RH; ++r) y[r] = v.y[r];
+            ynext = v.y[RH];
+        }
+    }
     store_outputs<RH>(g, outv, ch, M0 + (long long)o0, y, ynext, M0 + g.per_tile);
 }
 
@@ -1492,7 +1591,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             }
             // the tile before the last
             if (FIN != 1 && t_fin >= 0 && !(SDR_I8_ABL & 4))
-                i8_finish<(FIN == 2 ? R / 2 : R), NCB>(g, outv, (const float *)ybuf, p & 1, tid, t_fin);
+                i8_finish<(FIN == 2 ? R / 2 : R), NCB, S8>(g, outv, (const float *)ybuf, p & 1, tid, t_fin, in, ftaps);
             if (DYN && wave == 0 && lane == 0) q_drawn = i8_draw(qctr, 1u);
             clk.mark(2);
             const bool work = tile_of(p - 1) >= 0 && !(SDR_I8_ABL & 1);
@@ -1641,7 +1740,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             request(t_req, w, tl);
             clk.mark(1);
             if (FIN != 0 && t_fin >= 0 && !(SDR_I8_ABL & 4))
-                i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin);
+                i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB, S8>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin, in, ftaps);
             if constexpr (DYN) tq_snap = tq_in;
             clk.arrive();
             lds_only_barrier();
@@ -1650,7 +1749,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         I8Tile tl0, tl1;
         request(tile_of(0), w0, tl0);
         request(tile_of(1), w1, tl1);
-        if (ftaps) {
+        if (ftaps && g.store_from > g.out_begin) {
             // outputs [out_begin, store_from) of every channel: see i8_startup_fm_output; dealt over the
             // helper waves of the whole grid, done behind the first two requests (their loads are in flight meanwhile)
             const long long n_su = g.store_from - g.out_begin, total = n_su * (g.total_tiles / g.tiles_per_ch);
@@ -1827,7 +1926,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN>));                                  \
         fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale,                 \
-                                                                  g.store_from > g.out_begin ? p->d_ftaps : nullptr, qctr); \
+                                                                  p->d_ftaps, qctr); \
     } while (0)
         // (the dynamic order is instantiated where the rule above can choose it)
 #define SDR_I8Q(NS, CB, PRE, S8)                                                                 \

@@ -7,6 +7,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from parity_checks import check_fm, check_linear, apt_stage2  # noqa: E402  (tests/ is on sys.path under pytest)
+
 pytestmark = pytest.mark.gpu
 TWO_PI = 2.0 * np.pi
 
@@ -36,12 +38,13 @@ def test_reference_loop_through_shims(golden, oracle, tmp_path):
     x9f = np.fromfile(pfx + ".x9f.f32", np.float32).astype(np.float64)
     w6, w9 = golden["apt_x6"], golden["apt_x9"]
     assert x6.shape == w6.shape == x6f.shape and x9.shape == w9.shape == x9f.shape
-    tol = 1e-5 * 0.5
-    settle = 200 // 10 + 2          # near-zero |y| during the filter's start-up: ill-conditioned angles
-    s9 = settle // 15 + 2 + 195 // 15
+    h1, h2 = golden["apt_lpf_fm"], golden["apt_lpf_am"]
+    y4 = oracle.fir_decimate(oracle.unpack_scale_i16(golden["apt_iq"]), 10, h1)
+    s9 = (200 // 10 + 2) // 15 + 2 + 195 // 15
     for got6, got9 in ((x6, x9), (x6f, x9f)):
-        assert np.abs(got6 - w6)[settle:].max() <= tol
-        assert np.abs(got9 - w9)[s9:].max() <= tol
+        check_fm(got6, w6, y4, 1 / TWO_PI, "shim x6")                       # start-up transient included
+        check_linear(got9, apt_stage2(oracle, got6, 2400 / 62400.0, 15, h2), "shim x9")
+        assert np.abs(got9 - w9)[s9:].max() <= 1e-5 * 0.5
     # decimate_vec (rate 2.5) and filter_vec (7 taps) on the shim path's x6, against the oracle
     dec = np.fromfile(pfx + ".dec.f64", np.float64)
     want_dec, _, oob = oracle.decimate_vec(x6, 2.5)
@@ -98,17 +101,13 @@ def test_fm_loop_through_source_shim(oracle, tmp_path):
     assert n4 == 26215 and x5.size == (nblk - 1) * (n4 - 1) == x5raw.size
     na = (n4 - 2) // Da + 1
     assert pcm.size == (nblk - 1) * na
-    fs_full = abs(scale) * np.pi
     for b in range(nblk - 1):
         cf = oracle.unpack_scale_i16(iq[2 * blk * (b + 1): 2 * blk * (b + 2)]).astype(np.complex64).astype(np.complex128)
         y = oracle.fir_pick(cf, D, lpf)
         want5 = oracle.polar_discriminator(y, scale)
-        settle = 101 // D + 2                          # start-up transient: ill-conditioned angles (sdr_hip.h, rule 2)
         for got in (x5, x5raw):
             g = got[b * (n4 - 1): (b + 1) * (n4 - 1)]
-            d = np.abs(g - want5)
-            d = np.minimum(d, np.abs(2 * fs_full - d))
-            assert d[settle:].max() <= 1e-5 * fs_full, (b, float(d[settle:].max()))
+            check_fm(g, want5, y, scale, f"block {b}")  # every block's start-up transient included
         # audio chain on the kernel's own x5 (float32), AF seq count
         g5 = np.fromfile(pfx + ".x5.f32", np.float32)[b * (n4 - 1): (b + 1) * (n4 - 1)]
         _, want_pcm = oracle.fm_audio_chain(g5, h_de, h_a, Da, af_seq=True)
@@ -188,7 +187,6 @@ def test_file_replay(sdr, oracle, tmp_path, kind):
     xx = np.concatenate([x[:kept], x[:kept]])
     y = oracle.fir_decimate(xx, D, h)
     want = oracle.polar_discriminator(y, 1 / TWO_PI)
-    from test_gpu_parity import check_fm
     check_fm(got, want, y, 1 / TWO_PI, kind)
     # errors: missing file, file shorter than two blocks
     with pytest.raises(sdr.SdrError):

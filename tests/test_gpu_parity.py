@@ -28,42 +28,7 @@ def sdr():
     return sdr_amd
 
 
-def check_linear(got, want, what=""):
-    want = np.asarray(want)
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    if want.size == 0:
-        return
-    fs = max(1.0, float(np.abs(want).max()))
-    err = float(np.abs(got.astype(want.dtype) - want).max())
-    assert err <= 1e-5 * fs, (what, err, fs)
-
-
-def check_fm(got, want, y, scale, what=""):
-    """y: the oracle's complex decimated stream (len(want)+1)"""
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    if want.size == 0:
-        return
-    fs = abs(scale) * np.pi
-    turn = abs(scale) * TWO_PI
-    d = np.abs(got.astype(np.float64) - want)
-    d = np.minimum(d, np.abs(turn - d))
-    mag = np.abs(y)
-    rms = float(np.sqrt(np.mean(mag * mag))) if mag.size else 0.0
-    pair_min = np.minimum(mag[:-1], mag[1:])
-    exact = pair_min == 0.0
-    if exact.any():
-        # 0 or +-scale*pi, decided by the signs of the zeros: one float32 ulp of slack for the product
-        # scale*pi itself (float32(scale)*float32(pi) vs float32(scale*pi); exact for scale = 1/(2 pi))
-        ge, we = got[exact].astype(np.float64), want[exact].astype(np.float32).astype(np.float64)
-        nz = we != 0.0
-        assert np.array_equal(np.signbit(ge[nz]), np.signbit(we[nz])) and (ge[~nz] == 0.0).all(), what
-        assert np.abs(ge - we).max() <= 2.0 ** -23 * fs, (what, float(np.abs(ge - we).max()))
-    good = pair_min > 1e-3 * rms
-    if good.any():
-        assert float(d[good].max()) <= 1e-5 * fs, (what, float(d[good].max()))
-    weak = ~good & ~exact
-    if weak.any():
-        assert float(d[weak].max()) <= 1e-3 * fs + 1e-2 * fs * 0, (what, float(d[weak].max()))
+from parity_checks import check_fm, check_linear, apt_stage2  # noqa: E402  (tests/ is on sys.path under pytest)
 
 
 def test_unpack_bit_exact(sdr, golden):
@@ -131,18 +96,17 @@ def test_cfg1_fm_chain(sdr, oracle, golden):
     assert np.abs(env[::997].astype(np.float64) - golden["cfg1_env_stride"]).max() <= 1e-5
 
 
-def test_am_chain(sdr, golden):
+def test_am_chain(sdr, oracle, golden):
     got = sdr.FirPlan(golden["am_taps"], 20, mode=sdr.MODE_ENV).execute_host(golden["am_iq"])
     check_linear(got, golden["am_env"], "am env")
     got = sdr.FirPlan(golden["am_taps"], 5, mode=sdr.MODE_FM, scale=0.75).execute_host(golden["am_iq"])
-    want = golden["am_fm"]
-    d = np.abs(got.astype(np.float64) - want)
-    assert d[30:].max() <= 1e-5 * 0.75 * np.pi
+    y = oracle.fir_decimate(oracle.unpack_scale_i16(golden["am_iq"]), 5, golden["am_taps"])
+    check_fm(got, golden["am_fm"], y, 0.75, "am fm")       # the start-up transient included
 
 
 @pytest.mark.parametrize("pfx,h1,h2", [("apt", "apt_lpf_fm", "apt_lpf_am"),
                                        ("apt511", "apt511_h1", "apt511_h2")])
-def test_apt_two_stage(sdr, golden, pfx, h1, h2):
+def test_apt_two_stage(sdr, oracle, golden, pfx, h1, h2):
     """bladerf_apt_demod.cpp:728-754: FIR/10 + FM, then +2400/62400 shift, FIR/15, envelope.
     Stage 2 runs the fused real-input + NCO-mixer kernel on stage 1's device output."""
     iq = golden["apt_iq"]
@@ -162,10 +126,14 @@ def test_apt_two_stage(sdr, golden, pfx, h1, h2):
     x9 = d_x9.to_numpy(np.float32, n9).astype(np.float64)
     w6, w9 = golden[pfx + "_x6"], golden[pfx + "_x9"]
     assert x6.shape == w6.shape and x9.shape == w9.shape
-    T1 = golden[h1].size
-    settle = T1 // 10 + 2           # the filter's start-up transient has near-zero |y|: angles there are ill-conditioned
-    assert np.abs(x6[settle:] - w6[settle:]).max() <= 1e-5 * 0.5
-    assert np.abs(x9 - w9)[settle // 15 + 2 + golden[h2].size // 15:].max() <= 1e-5 * 0.5
+    # stage 1 over the whole block, start-up transient included, by the discriminator's bars
+    y4 = oracle.fir_decimate(oracle.unpack_scale_i16(iq), 10, golden[h1])
+    check_fm(x6, w6, y4, 1 / TWO_PI, pfx + " x6")
+    # stage 2 against the reference's arithmetic on the same x6, and against the golden x9 where the
+    # transient's (legitimately different) angles have left the second filter
+    check_linear(x9, apt_stage2(oracle, x6, 2400 / 62400.0, 15, golden[h2]), pfx + " x9")
+    s9 = (golden[h1].size // 10 + 2) // 15 + 2 + golden[h2].size // 15
+    assert np.abs(x9 - w9)[s9:].max() <= 1e-5 * 0.5
 
 
 @pytest.mark.parametrize("T,D", [(64, 10), (101, 5), (101, 20), (200, 10), (195, 15), (511, 10),
@@ -815,9 +783,11 @@ def test_int8_matrix_kernel_shards_and_channels(sdr, oracle):
             plan.execute_range_dev(d_blk, lo, hi - lo, n, ob, oe, d_out)
             sdr.sync()
             parts.append(d_out.to_numpy(np.float32, oe - ob))
-        got = np.concatenate(parts).astype(np.float64)
-        settle = T // D + 2
-        assert np.abs(got - want)[settle:].max() <= 1e-5 * 0.5, mode
+        got = np.concatenate(parts)
+        if mode == sdr.MODE_FM:
+            check_fm(got, want, oracle.chain_i16(iq, D, h, oracle.MODE_IQ), 1 / TWO_PI, "i8 shards fm")
+        else:
+            check_linear(got, want, "i8 shards env")
     # ---- channel-major batch -------------------------------------------------------------------
     n_ch, nc = 9, 30_007
     stride_in = nc + 40
@@ -955,7 +925,7 @@ def test_matrix_kernel_startup_zero_vector_angle(sdr, oracle, pipe):
     assert y[0] == 0 and y[1] != 0 and abs(want[0]) == 0.5
     got = plan.execute_host(iq)
     assert got[0] == np.float32(want[0])
-    check_fm(got[T:], want[T:], y[T:], 1 / TWO_PI, "past the transient")
+    check_fm(got, want, y, 1 / TWO_PI, "whole stream")
 
 
 @pytest.mark.gpu
@@ -1026,45 +996,83 @@ def test_pipeline5_refuses_one_tap(sdr):
 
 
 @pytest.mark.gpu
-def test_pipeline5_zero_run_deviation(sdr, oracle):
-    """The one documented deviation of the int8 matrix kernel (sdr_hip.h, SDR_MODE_FM exemption 3):
-    taps below 2^-31 of the largest tap vanish in its fixed point.  After >= T zero samples in
-    mid-stream, the output whose window meets the first non-zero sample only through such a tap has
-    y == 0 there and a tiny y in the reference, so that output and its predecessor report the angle of
-    a zero vector.  Everything else is within the usual bars, and the vector-unit kernel has no such
-    deviation."""
-    T, D = 64, 1
-    rng = np.random.default_rng(9)
-    h = oracle.create_fir_filter(T, 0.3, "hann")
-    h[0] = 1e-13                                   # sub-resolution, but not zero (Hann gives an exact 0 here)
+@pytest.mark.parametrize("T,D,kind", [(64, 1, "i16"), (64, 10, "i16"), (511, 10, "i16"), (200, 4, "i16"), (300, 20, "i16"),
+                                      (64, 10, "i8"), (255, 4, "i8"), (64, 10, "qi")])
+def test_matrix_kernel_zero_runs(sdr, oracle, T, D, kind):
+    """Round 2's header carried an exemption for the int8 matrix kernel: taps below 2^-31 of the largest
+    tap vanish in its fixed point, so after >= T zero samples in mid-stream the output whose window meets
+    the first non-zero sample only through such a tap was an exact 0 there and a tiny vector in the
+    reference, and two discriminator outputs reported a zero vector's angle.  The kernel now recomputes
+    every exactly-zero y that feeds a stored output with float32 taps (i8_zero_fix), so the whole stream
+    -- the run's 0 / +-pi outputs included, which check_fm demands exactly -- holds the bars, for the
+    pinned and the automatic choice, one piece or sharded."""
+    rng = np.random.default_rng(T * 7 + D)
+    h = oracle.create_fir_filter(T, min(0.8 / D, 0.45), "hann")
+    # sub-resolution taps at both ends and inside (a windowed sinc's numerical zeros), none exactly zero
+    h[0], h[1], h[-1] = 1e-13, -3e-14, 2e-15
+    h[T // 3] = -1e-14
     assert 0 < abs(h[0]) < np.abs(h).max() * 2.0 ** -31
-    n = 20_000
-    iq = rng.integers(-2000, 2001, 2 * n, dtype=np.int16)
-    z0, z1 = 9_000, 9_000 + 3 * T                  # a run of 3T zero samples in mid-stream
-    iq[2 * z0: 2 * z1] = 0
-    iq[2 * z1] = 1500; iq[2 * z1 + 1] = -700       # the first sample after the run
-    y = oracle.fir_decimate(oracle.unpack_scale_i16(iq), D, h)
+    n = 40 * 1024 + 1234 + 7 * D
+    if kind == "i8":
+        raw = rng.integers(-128, 128, 2 * n).astype(np.int8)
+        inp, unpack = sdr.IN_I8_IQ, oracle.unpack_scale_i8
+    else:
+        raw = rng.integers(-2000, 2001, 2 * n).astype(np.int16)
+        inp, unpack = (sdr.IN_I16_QI if kind == "qi" else sdr.IN_I16_IQ), \
+                      (oracle.unpack_scale_i16_qi if kind == "qi" else oracle.unpack_scale_i16)
+    # zero runs in mid-stream: longer than the filter (several, at odd alignments, one crossing a tile
+    # border of 1024 outputs), one shorter than the filter, and isolated samples inside a long run
+    runs = [(3_000, 3_000 + 3 * T + 5), (1024 * D - T - 3, 1024 * D + 2 * T + 1), (9_001, 9_001 + T - 7),
+            (15_000 + D // 2, 15_000 + 4 * T + 2 * D)]
+    runs = [(a, b) for a, b in runs if b < n - 2 * T]
+    for i, (a, b) in enumerate(runs):
+        # ends on an output's sample (that output sees the first sample behind the run through h[0] only)
+        # or one before it (h[0] and h[1]); starts so that some output sees the last sample before the
+        # run through h[T-1] only
+        b = (b + D - 1) // D * D - (i & 1)
+        a -= (a + T - 2) % D
+        raw[2 * a: 2 * b] = 0
+    z0 = 20_000
+    z1 = min(n - 3 * T, z0 + 12 * T + 40 * D)
+    raw[2 * z0: 2 * z1] = 0
+    for k, s in enumerate(range(z0 + T + 3, z1 - T, 2 * T + 3 * D + 1)):   # lone samples: every window sees at most one
+        raw[2 * s] = (-1) ** k * 77
+        raw[2 * s + 1] = 55 if k % 3 else -91
+    y = oracle.fir_decimate(unpack(raw), D, h)
     want = oracle.polar_discriminator(y, 1 / TWO_PI)
-    m0 = z1                                        # y[m0] = h[0] * x[z1] only
-    assert y[m0 - 1] == 0 and y[m0] != 0 and abs(y[m0]) < 1e-12
-    p5 = sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=5)
-    p1 = sdr.FirPlan(h, D, mode=sdr.MODE_FM, pipeline=1)
-    assert p5.info()["kernel"] == "mfma_i8" and p1.info()["kernel"] == "raw_tile"
-    g5, g1 = p5.execute_host(iq), p1.execute_host(iq)
-    # vector-unit kernel: float32 taps keep h[0], so the whole stream is within the bars (the run's
-    # zero-vector angles included, which check_fm demands exactly)
-    check_fm(g1, want, y, 1 / TWO_PI, "raw tile across the zero run")
-    # matrix kernel: the two outputs that involve y[m0] may differ (and then are a zero vector's angle);
-    # everything else holds the bars
-    dev = np.array([m0 - 1, m0])
-    keep = np.ones(want.size, bool)
-    keep[dev] = False
-    segs = [(0, m0 - 1), (m0 + 1, want.size)]
-    for a, b in segs:
-        check_fm(g5[a:b], want[a:b], y[a:b + 1], 1 / TWO_PI, f"matrix kernel outside the deviation [{a},{b})")
-    assert set(np.abs(g5[dev]).tolist()) <= {0.0, 0.5}, g5[dev]
-    # the deviation is real (if this starts failing the header's exemption 3 can go)
-    assert not np.array_equal(g5[dev].astype(np.float64), want[dev].astype(np.float32).astype(np.float64))
+    mag = np.abs(y)
+    tiny = (mag > 0) & (mag < 1e-11)
+    assert tiny.sum() >= 3 and (mag == 0).sum() >= 3 * T // D      # the case is in the stream, several times
+    for pipe in (5, 0):
+        plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=inp, pipeline=pipe)
+        if pipe == 5:
+            assert plan.info()["kernel"] == "mfma_i8"
+        got = plan.execute_host(raw)
+        # (noise input: |y| has no typical magnitude, so every output gets the angle bound -- good_rel=None)
+        check_fm(got, want, y, 1 / TWO_PI, f"zero runs {T}/{D} {kind} pipe {pipe}", good_rel=None)
+        # outputs that involve a tiny y are bit-equal to what the vector-unit arithmetic gives, and the
+        # shards reproduce the one-piece result bit for bit
+        cnt = got.size
+        esz = 2 if kind == "i8" else 4
+        d_all = sdr.DevBuf.from_numpy(raw)
+        parts = []
+        for ob, oe in ((0, cnt // 3), (cnt // 3, cnt // 2 + 11), (cnt // 2 + 11, cnt)):
+            lo = max(0, ob * D - (T - 1))
+            hi = min(n, (oe + 1) * D + 1)
+            d_out = sdr.DevBuf(max(oe - ob, 1) * 4)
+            plan.execute_range_dev(d_all.at(esz * lo), lo, hi - lo, n, ob, oe, d_out)
+            sdr.sync()
+            parts.append(d_out.to_numpy(np.float32, oe - ob))
+        assert np.array_equal(np.concatenate(parts), got)
+    # the other modes see the same zeros (no recomputation there: an exact 0 is within the linear bar)
+    check_linear(sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=inp, pipeline=5).execute_host(raw), np.abs(y), "zero runs env")
+    # an all-zero stream stays all zero (exact), and a stream that is zero but for its last sample
+    z = np.zeros_like(raw)
+    p5 = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=inp, pipeline=5)
+    assert not p5.execute_host(z).any()
+    z[-2:] = (5, -3)
+    yz = oracle.fir_decimate(unpack(z), D, h)
+    check_fm(p5.execute_host(z), oracle.polar_discriminator(yz, 1 / TWO_PI), yz, 1 / TWO_PI, "zero but for the last sample", good_rel=None)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Same-box A/B of two builds of libsdrhip: this tree's sdr_amd/libsdrhip.so against another .so (e.g. the
+previous round's build kept as sdr_amd/libsdrhip_r02.so), interleaved, one child process per
+measurement (a process binds one library).  usage: ab_libs.py <other.so> [rounds]
+Each child times a list of FIR shapes (FM unless stated) and prints JSON; the parent tabulates."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPES = [  # log2n, T, D, mode, input, pipeline
+    (30, 64, 10, 1, 0, 0), (28, 64, 10, 1, 0, 0), (28, 64, 10, 2, 0, 0), (28, 64, 10, 0, 0, 0), (26, 511, 10, 1, 0, 0), (28, 511, 10, 1, 0, 0),
+    (28, 200, 10, 1, 0, 0), (28, 101, 5, 1, 0, 0), (28, 64, 4, 1, 0, 0), (28, 300, 25, 1, 0, 0), (28, 64, 10, 1, 4, 0), (28, 511, 10, 1, 4, 0),
+    (28, 64, 10, 1, 0, 1),
+]
+
+
+def child():
+    sys.path.insert(0, ROOT)
+    import sdr_amd
+    sdr_amd.init(0)
+    n_max = 1 << 30
+    d_in = sdr_amd.DevBuf(n_max * 4 + 64)
+    sdr_amd.capi.synth_fm_i16_dev(d_in, n_max, fs=20e6, noise_lsb=8)
+    d_out = sdr_amd.DevBuf((n_max // 4 + 64) * 8)
+    out = []
+    for (l2, T, D, mode, inp, pipe) in SHAPES:
+        n = 1 << l2
+        h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
+        p = sdr_amd.FirPlan(h, D, mode=mode, input=inp, pipeline=pipe)
+        # warm the clocks: batches until two agree within 1 %
+        prev = None
+        for _ in range(12):
+            cur = p.time_dev(d_in, n, d_out, 20)
+            if prev is not None and abs(cur - prev) <= 0.01 * prev:
+                break
+            prev = cur
+        ms = sorted(p.time_dev(d_in, n, d_out, 10) for _ in range(5))
+        out.append({"shape": [l2, T, D, mode, inp, pipe], "ms_min": ms[0], "ms_med": ms[2], "kernel": p.info()["kernel"]})
+        p.destroy()
+    print("AB " + json.dumps(out), flush=True)
+
+
+def main():
+    other = os.path.abspath(sys.argv[1])
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    res = {"new": [], "old": []}
+    for r in range(rounds):
+        for name, lib in (("old", other), ("new", None), ("new", None), ("old", other)):
+            env = dict(os.environ)
+            if lib:
+                env["SDRHIP_LIB"] = lib
+            else:
+                env.pop("SDRHIP_LIB", None)
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=280)
+            if cp.returncode != 0:
+                print(cp.stdout[-2000:], cp.stderr[-2000:])
+                sys.exit(cp.returncode or 1)
+            line = [l for l in cp.stdout.splitlines() if l.startswith("AB ")][-1]
+            res[name].append(json.loads(line[3:]))
+    print("shape (log2n T D mode input pipe)    kernel     old min / med      new min / med      new/old (min)")
+    for i, sh in enumerate(SHAPES):
+        o_min = min(r[i]["ms_min"] for r in res["old"]); n_min = min(r[i]["ms_min"] for r in res["new"])
+        o_med = sorted(r[i]["ms_med"] for r in res["old"])[len(res["old"]) // 2]
+        n_med = sorted(r[i]["ms_med"] for r in res["new"])[len(res["new"]) // 2]
+        print(f"{str(sh):36s} {res['new'][0][i]['kernel']:9s} {o_min:8.4f} {o_med:8.4f}   {n_min:8.4f} {n_med:8.4f}   {n_min / o_min:6.3f}")
+
+
+if __name__ == "__main__":
+    if "--child" in sys.argv:
+        child()
+    else:
+        main()

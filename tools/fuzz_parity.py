@@ -14,28 +14,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import sdr_amd as sdr                      # noqa: E402
 from oracle import oracle                  # noqa: E402
-from test_gpu_parity import check_linear, TWO_PI   # noqa: E402  (helpers only; pytest collects nothing from here)
+from parity_checks import check_linear, TWO_PI   # noqa: E402
+from parity_checks import check_fm as _check_fm  # noqa: E402
 
 
 def check_fm(got, want, y, scale, what=""):
-    """Discriminator outputs against the oracle with a bound that follows from the linear one: an
-    error e <= 1e-5 * FS on y[m] and y[m+1] moves the angle by at most e/|y[m]| + e/|y[m+1]|.
-    Outputs whose y is exactly zero in the oracle must match exactly (0 or +-pi*scale)."""
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    if want.size == 0:
-        return
-    fs = abs(scale) * np.pi
-    d = np.abs(got.astype(np.float64) - want)
-    d = np.minimum(d, np.abs(2 * fs - d))
-    mag = np.abs(y)
-    pm = np.minimum(mag[:-1], mag[1:])
-    exact = pm == 0.0
-    if exact.any():
-        assert np.array_equal(got[exact].astype(np.float64), want[exact].astype(np.float32).astype(np.float64)), what + " exact zeros"
-    e = 1e-5 * max(1.0, float(mag.max()))
-    allowed = abs(scale) * 2.0 * e / np.maximum(pm, 1e-300) + 1e-5 * fs
-    bad = ~exact & (d > allowed)
-    assert not bad.any(), (what, int(bad.sum()), float(d[bad].max()))
+    """the bars of include/sdr_hip.h with the angle bound on every output (random taps, noise inputs)"""
+    _check_fm(got, want, y, scale, what, good_rel=None)
 
 
 def random_taps(rng, T, D):

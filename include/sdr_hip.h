@@ -26,9 +26,12 @@
  *     (SDR_EINVAL otherwise).  Plans are immutable after creation except for the staging /
  *     scratch buffers of the *_host entry points and of FFT frames longer than 4096 points:
  *     those calls are one at a time per plan; *_dev calls of one plan may be enqueued on several
- *     streams (the int8 matrix kernel keeps one block of tile counters per stream that launches a
- *     plan, eight per plan; further streams, and launches under HIP stream capture, run with the
- *     static tile order -- same results, a few per cent slower on long launches).  The last-error
+ *     streams (long launches of the int8 matrix kernel take one block of tile counters each from
+ *     a ring of 64 per plan; a block goes to a launch on another stream only after its previous
+ *     launch has reported completion, so launches that may overlap never share one, whatever their
+ *     stream handles -- hipStreamPerThread from several threads included; with no block free, and
+ *     under HIP stream capture, a launch runs the static tile order: same results, a few per cent
+ *     slower).  The last-error
  *     text is per thread.
  */
 #ifndef SDR_HIP_H_
@@ -60,26 +63,22 @@ enum sdr_status {
  *   IQ, ENV, REAL  |err| <= e = 1e-5 * FS, FS = max(1, max|y|) (Q11 full scale is 1.0).  No exemption.
  *   FM             full scale is scale*pi (0.5 for scale 1/(2*pi)); outputs compare modulo one turn.
  *                  The output is the ANGLE of y[m+1]*conj(y[m]), so the linear bound e on y turns into
- *                  scale*(e/|y[m]| + e/|y[m+1]|) on the angle.  That is within 1e-5 of full scale wherever
- *                  both |y| exceed 1e-3 of the block's rms, and the tests demand 1e-5 there.  Three
- *                  documented exemptions, all "the angle of a (nearly) zero vector":
- *                  (1) ill-conditioned angles: where |y[m]| or |y[m+1]| is below 1e-3 of the block rms
- *                      the bound is the one above (the tests allow 1e-3 of full scale); any float32
- *                      evaluation, the reference's own ArrayFire path included, moves these outputs;
- *                  (2) start-up transient: the first ceil((T-1)/D)+1 outputs of a stream come from
- *                      partly filled windows (zero pre-history, bladerf_apt_demod.cpp:299-305) and are
- *                      small, so rule (1) usually applies to them; nothing else is special about them.
- *                      Where y[m] is EXACTLY zero the reference's 0 / +-pi (from the signs of its zeros,
- *                      bladerf_apt_demod.cpp:419-421) is reproduced bit for bit by every kernel;
- *                  (3) pipeline 5 only (the int8 matrix kernel, which the automatic choice takes for most
- *                      int16 and int8 shapes; pin pipeline 1 or 2 to rule it out): taps below 2^-31 of the
- *                      largest tap vanish in its fixed point.
- *                      After a run of >= T zero samples in mid-stream, the first output whose window
- *                      meets a non-zero sample ONLY through such taps has y == 0 here and a tiny y in
- *                      the reference: that output and its predecessor report the angle of a zero vector
- *                      (0 or +-scale*pi) instead of the reference's.  At a stream's start the same
- *                      situation is repaired (recomputed with float32 taps); in mid-stream it is not.
- *                      Pinned by tests/test_gpu_parity.py::test_pipeline5_zero_run_deviation. */
+ *                  scale*(asin(e/|y[m]|) + asin(e/|y[m+1]|)) on the angle (~ scale*(e/|y[m]| + e/|y[m+1]|);
+ *                  a vector shorter than e can point anywhere).  On the constant-envelope FM test signals
+ *                  the tests demand 1e-5 of full scale wherever both |y| exceed 1e-3 of the block's rms,
+ *                  and this bound everywhere else (noise inputs: this bound everywhere).  Two remarks, both
+ *                  "the angle of a (nearly) zero vector", neither an exemption from the bound:
+ *                  (1) start-up transient: the first ceil((T-1)/D)+1 outputs of a stream come from partly
+ *                      filled windows (zero pre-history, bladerf_apt_demod.cpp:299-305) and are small, so
+ *                      the bound is wide there; nothing else is special about them;
+ *                  (2) where y[m] or y[m+1] is EXACTLY zero in the reference (zero pre-history, a run of
+ *                      >= T zero samples in mid-stream) its output is 0 or +-scale*pi by the signs of its
+ *                      zeros (bladerf_apt_demod.cpp:419-421): reproduced bit for bit by every kernel.  The
+ *                      int8 matrix kernel (pipeline 5), whose fixed-point taps lose anything below 2^-31 of
+ *                      the largest tap, recomputes with float32 taps every output of its own that came out
+ *                      as an exact zero over a window that is not all zero, at a stream's start and in
+ *                      mid-stream alike (round 2 documented the mid-stream case as a deviation; it is gone:
+ *                      tests/test_gpu_parity.py::test_matrix_kernel_zero_runs). */
 enum sdr_mode {
     SDR_MODE_IQ = 0,    /* complex y[m] (float2)           -- polyphase_decimate alone        */
     SDR_MODE_FM = 1,    /* scale*arg(y[m+1] conj(y[m]))    -- + polar_discriminator           */
@@ -189,8 +188,9 @@ typedef struct sdr_fir_desc {
                              (tiles vs taps per sample) puts it ahead -- everywhere but small decimation
                              factors with few taps.  Taps
                              smaller than 2^-31 of the largest one are dropped by the fixed point;
-                             the discriminator outputs of a stream's start-up transient, where
-                             such taps can decide the angle, are recomputed with float32 taps.
+                             discriminator outputs that such taps alone decide (a y that is exactly
+                             zero in fixed point over a window that is not) are recomputed with
+                             float32 taps, at a stream's start and after zero runs in mid-stream.
                              6 = K-split float tiles for SHORT real-input streams (SDR_IN_F32_REAL, any
                              mode but FM; 4 outputs per lane, 256 threads): the four waves of a workgroup
                              walk a quarter of the filter each and add their partial sums in a fixed

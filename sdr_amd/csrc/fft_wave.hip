@@ -328,23 +328,28 @@ int measurement_flags_fft_wave() { return 0; }
 int launch_fft4096_wave(const uint32_t *iq, const float *win, const cf *tw, float *out, const FftGeom &g,
                         int n_cu, bool two, hipStream_t st)
 {
-    static std::atomic<bool> opted{false};         // the kernels' dynamic LDS limit, raised once per process
+    // the kernels' dynamic LDS limit is raised once per DEVICE (the attribute belongs to the function as
+    // loaded on one device; a process may drive several GPUs); the flag is set after a successful launch
+    constexpr int kMaxDevices = 64;
+    static std::atomic<bool> opted_dev[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
     FftGeom gw = g;
     const int nw = two ? 8 : 4;
     const long long waves = (long long)nw * n_cu;
     gw.chunk = (g.frames + waves - 1) / waves;
     const unsigned nb = (unsigned)(((g.frames + gw.chunk - 1) / gw.chunk + nw - 1) / nw);
     const size_t lds = 4096 * sizeof(float) + (two ? 8 * (size_t)(32 * 66 * 8) + 14 * 64 * 8 + 64 : 4 * (size_t)(64 * 66 * 8));
-    if (!opted.load(std::memory_order_relaxed)) {
+    if (dev < 0 || !opted_dev[dev].load(std::memory_order_relaxed)) {
         hipError_t ea = hipFuncSetAttribute((const void *)fft4096_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea == hipSuccess) ea = hipFuncSetAttribute((const void *)fft4096_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) of the fft wave kernel");
-        opted.store(true, std::memory_order_relaxed);
     }
     if (two) fft4096_wave_kernel<true><<<nb, 512, lds, st>>>(iq, win, tw, out, gw);
     else fft4096_wave_kernel<false><<<nb, 256, lds, st>>>(iq, win, tw, out, gw);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "fft wave kernel launch");
+    if (dev >= 0) opted_dev[dev].store(true, std::memory_order_relaxed);
     return SDR_OK;
 }
 

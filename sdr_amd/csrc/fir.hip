@@ -83,6 +83,7 @@ struct FirGeom {
     int total_tiles;
     int ph_off;             // mixer: offset (floats) of the phasor tables behind the tap table
     int n_ph_hi;            // mixer: entries of the coarse table (tile offsets 0, 64, 128, ...)
+    int zfix;               // fir_mfma_i8_kernel, discriminator: some tap is below the fixed-point resolution (see i8_zero_fix)
 };
 
 // kernel-side input kinds (Q-first int16 is IN_I16 with FirGeom::swap_iq)
@@ -1068,7 +1069,9 @@ fir_mfma_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 // over the WHOLE window.  The four exact integers of an output are combined in float32 once; the +128
 // of the low bytes comes back as 128 * (sum of the row's digits), combined the same way.  No rounding
 // before that step, zero samples give exact zeros, and an output's bits depend neither on the tile
-// it falls into nor on how the stream is cut into launches or shards.
+// it falls into nor on how the stream is cut into launches or shards.  (Discriminator plans whose tap
+// set has a tap below the fixed-point resolution look at their exactly-zero outputs again, with
+// float32 taps: i8_zero_fix.)
 // Staging is eight byte permutes per four samples -- no conversions.
 //
 // 512 lanes, two waves per SIMD with 256 registers each, in two roles.  Waves 0-3 ("matrix waves")
@@ -1446,12 +1449,20 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
         y[0] = make_float2(pa[0], pa[4 * 33]);
     }
     ynext = make_float2(pb[0], pb[4 * 33]);
-    if (g.mode == SDR_MODE_FM) {
-        // an exact zero among the y this lane's outputs read: see i8_zero_fix (rare: one compare per lane)
-        float mn = fmaxf(fabsf(ynext.x), fabsf(ynext.y));
+    // Plans whose taps include one that the fixed point rounds to zero (FirGeom::zfix, decided at plan
+    // creation) look for exact zeros among the y this lane's outputs read: see i8_zero_fix.  The outputs
+    // are stored first and stored again in the rare case that a y changes (the same wave's stores to one
+    // address keep their order): a branch in front of the discriminator would split the block the
+    // scheduler overlaps the LDS reads and the arctangents in.
+    store_outputs<RH>(g, outv, ch, M0 + (long long)o0, y, ynext, M0 + g.per_tile);
+    if (g.zfix) {
+        // the matrix waves' combination never yields -0, so "both components zero" is "both words zero":
+        // one OR per output, one unsigned minimum over three of them (in this kernel every vector
+        // instruction of a tile is paid for, whichever wave issues it)
+        unsigned mn = __float_as_uint(ynext.x) | __float_as_uint(ynext.y);
 #pragma unroll
-        for (int r = 0; r < RH; ++r) mn = fminf(mn, fmaxf(fabsf(y[r].x), fabsf(y[r].y)));
-        if (__builtin_expect(__ballot(mn == 0.f) != 0ULL, 0)) {
+        for (int r = 0; r < RH; ++r) mn = min(mn, __float_as_uint(y[r].x) | __float_as_uint(y[r].y));
+        if (__builtin_expect(__ballot(mn == 0u) != 0ULL, 0)) {
             const long long tile_end = M0 + g.per_tile;
             I8Ys<RH> v;
 #pragma unroll
@@ -1459,12 +1470,13 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
             v.y[RH] = ynext;
             v = i8_zero_fix<RH, S8>(i8_chan<S8>(in, ftaps, g, ch), M0 + (long long)o0, g.store_from,
                                     tile_end < g.out_end ? tile_end : g.out_end, v);
+            bool changed = v.y[RH].x != ynext.x || v.y[RH].y != ynext.y;
 #pragma unroll
-            for (int r = 0; r < RH; ++r) y[r] = v.y[r];
+            for (int r = 0; r < RH; ++r) { changed |= v.y[r].x != y[r].x || v.y[r].y != y[r].y; y[r] = v.y[r]; }
             ynext = v.y[RH];
+            if (__ballot(changed) != 0ULL) store_outputs<RH>(g, outv, ch, M0 + (long long)o0, y, ynext, M0 + g.per_tile);
         }
     }
-    store_outputs<RH>(g, outv, ch, M0 + (long long)o0, y, ynext, M0 + g.per_tile);
 }
 
 // NS = k steps of the window, rounded up to a multiple of four (steps past the window carry zero taps
@@ -1478,7 +1490,7 @@ __global__ void __launch_bounds__(512, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
                    const int plane_bytes, const float yscale, const float *__restrict__ ftaps,
-                   unsigned *__restrict__ qctr)
+                   unsigned *__restrict__ qctr, unsigned *__restrict__ q_done, const unsigned q_gen)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -1767,12 +1779,16 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         n_ph = p;
     }
     // the last workgroup to get here zeroes the counters for the next launch (every draw of a workgroup
-    // precedes its own count here)
+    // precedes its own count here) and then tells the host, through a word of pinned host memory, that
+    // this launch (generation q_gen) has let go of the block: only then is the block handed to a launch
+    // on another stream (launch_r)
     if (DYN && tid == 0) {
         __threadfence();
         if (atomicAdd(&qctr[32 * 8], 1u) == gridDim.x - 1) {
 #pragma unroll
             for (int x = 0; x < 9; ++x) atomicExch(&qctr[32 * x], 0u);
+            __threadfence_system();
+            __hip_atomic_store(q_done, q_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     clk.flush(outv, g.out_end - g.out_begin, n_ph);
@@ -1802,15 +1818,25 @@ struct sdr_fir_plan {
     bool mfma_i8 = false;   // fir_mfma_i8_kernel (byte-split Toeplitz GEMM on the int8 matrix pipe, persistent)
     uint4 *d_atab8 = nullptr;   // its A-operand table (tap digits)
     uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave
-    // tile counters of its dynamic hand-out (i8_draw): one block of kI8QueueWords per stream that launches
-    // the plan, so that launches enqueued on several streams never share one (launches of one stream run
-    // one after the other; the last workgroup of each leaves the block zeroed)
-    unsigned *d_i8q = nullptr;
-    static constexpr int kQueueStreams = 8;
+    // Tile counters of its dynamic hand-out (i8_draw): a ring of kQueueBlocks blocks of kI8QueueWords, one
+    // block per LAUNCH, taken in turn, so that launches which may run at the same time never share one (the
+    // last workgroup of a launch leaves its block zeroed and writes the launch's generation to q_done, a
+    // word of pinned host memory per block).  A block is handed out again when its last launch has
+    // reported done, or -- still pending -- to a launch on the same ordinary stream handle, which runs
+    // behind it in stream order.  Not by handle alone: hipStreamPerThread names a different stream in every
+    // host thread, so for that handle (and hipStreamLegacy) only "done" counts.  No block free: static
+    // order for that launch.  Allocated at the first launch that qualifies (long launches only).
+    mutable unsigned *d_i8q = nullptr;
+    mutable unsigned *h_q_done = nullptr;       // pinned, mapped: [kQueueBlocks]
+    static constexpr int kQueueBlocks = 64;
     mutable std::mutex q_mu;
-    mutable hipStream_t q_stream[kQueueStreams] = {};
-    mutable int q_used = 0;
-    float *d_ftaps = nullptr;   // float32 taps (Q11 folded) for i8_startup_fm_output (discriminator plans)
+    mutable hipStream_t q_handle[kQueueBlocks] = {};
+    mutable unsigned q_gen[kQueueBlocks] = {};  // generation of the block's last launch (0: never used)
+    mutable unsigned q_next_gen = 0;
+    mutable int q_ring = 0;
+    mutable bool q_failed = false;              // the allocation failed once: static order from then on
+    float *d_ftaps = nullptr;   // float32 taps (Q11 folded) for i8_startup_fm_output / i8_zero_fix (discriminator plans)
+    bool zfix = false;          // a non-zero tap rounds to zero in the fixed point: exact-zero outputs are looked at again (i8_zero_fix)
     int plane_bytes = 0;
     float yscale = 1.f;         // its output scale 2^-(F+11)
     sdr_fir_plan *tiny = nullptr;   // automatic choice only: the VALU plan that takes streams shorter than 4 samples
@@ -1905,20 +1931,46 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         // 200 / 10 from box to box; int8 sample pairs, half the bytes per tile: +-1 %), on a grid of whole
         // XCD groups.  int16 shapes inside the rule, 2^30 samples, same box: 64/8 -8 %, 96/9 -10 %, 64/10
         // -9 %, 100/10 -9 %, 64/11 -6 %, 64/12 -7 %, 40/14 -5 %, 30/15 0 %.  Launches under
-        // stream capture (a replayed graph may run on any stream, beside anything) and streams beyond
-        // the plan's eight counter blocks keep the static order.
-        unsigned *qctr = nullptr;
+        // stream capture (a replayed graph may run on any stream, beside anything) and launches that find
+        // the next counter block of the plan's ring still in use by another stream (sdr_fir_plan::d_i8q)
+        // keep the static order.
+        unsigned *qctr = nullptr, *q_done = nullptr;
+        unsigned q_gen = 0;
         static const bool static_order = std::getenv("SDRHIP_STATIC_TILES") != nullptr;   // A/B measurements
-        if (p->d_i8q && !static_order && p->R == 4 && pre > 4 && p->ngran <= 4 && p->input != SDR_IN_I8_IQ && (nb & 7) == 0 && g.total_tiles >= 128LL * nb) {
+        if (!static_order && p->R == 4 && pre > 4 && p->ngran <= 4 && p->input != SDR_IN_I8_IQ && (nb & 7) == 0 && g.total_tiles >= 128LL * nb) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
             if (cs == hipStreamCaptureStatusNone) {
                 std::lock_guard<std::mutex> lk(p->q_mu);
-                int slot = -1;
-                for (int i = 0; i < p->q_used; ++i)
-                    if (p->q_stream[i] == st) slot = i;
-                if (slot < 0 && p->q_used < sdr_fir_plan::kQueueStreams) { slot = p->q_used++; p->q_stream[slot] = st; }
-                if (slot >= 0) qctr = p->d_i8q + (size_t)slot * kI8QueueWords;
+                if (!p->d_i8q && !p->q_failed) {
+                    const size_t qb = (size_t)sdr_fir_plan::kQueueBlocks * kI8QueueWords * sizeof(unsigned);
+                    unsigned *dq = nullptr, *hd = nullptr;
+                    hipError_t ea = hipMalloc((void **)&dq, qb);
+                    if (ea == hipSuccess) ea = hipMemset(dq, 0, qb);
+                    if (ea == hipSuccess) ea = hipHostMalloc((void **)&hd, sdr_fir_plan::kQueueBlocks * sizeof(unsigned), hipHostMallocMapped);
+                    if (ea == hipSuccess) {
+                        std::memset(hd, 0, sdr_fir_plan::kQueueBlocks * sizeof(unsigned));
+                        p->d_i8q = dq; p->h_q_done = hd;
+                    } else {
+                        (void)hipGetLastError();
+                        if (dq) (void)hipFree(dq);
+                        p->q_failed = true;
+                    }
+                }
+                if (p->d_i8q) {
+                    const int b = p->q_ring;
+                    const bool done = p->q_gen[b] == 0 ||
+                                      __atomic_load_n((const volatile unsigned *)&p->h_q_done[b], __ATOMIC_ACQUIRE) == p->q_gen[b];
+                    const bool ordinary = st != hipStreamPerThread && st != hipStreamLegacy;
+                    if (done || (ordinary && p->q_handle[b] == st)) {
+                        p->q_ring = (b + 1) % sdr_fir_plan::kQueueBlocks;
+                        if (++p->q_next_gen == 0) ++p->q_next_gen;
+                        p->q_gen[b] = q_gen = p->q_next_gen;
+                        p->q_handle[b] = st;
+                        qctr = p->d_i8q + (size_t)b * kI8QueueWords;
+                        q_done = p->h_q_done + b;
+                    }
+                }
             }
         }
 #define SDR_I8K(NS, CB, PRE, S8, DYN)                                                            \
@@ -1926,7 +1978,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN>));                                  \
         fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale,                 \
-                                                                  p->d_ftaps, qctr); \
+                                                                  p->d_ftaps, qctr, q_done, q_gen); \
     } while (0)
         // (the dynamic order is instantiated where the rule above can choose it)
 #define SDR_I8Q(NS, CB, PRE, S8)                                                                 \
@@ -2030,6 +2082,7 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.s_gran = p->s_gran; g.a_gran = p->a_gran; g.n_inst = p->n_inst; g.mode = p->mode;
     g.swap_iq = (p->input == SDR_IN_I16_QI) ? 1 : 0;
     g.ph_off = p->ph_off; g.n_ph_hi = p->n_ph_hi;
+    g.zfix = (p->mfma_i8 && p->mode == SDR_MODE_FM && p->zfix) ? 1 : 0;
     g.scale = (float)p->scale;
     // with the discriminator a tile's last lane only supplies its neighbour's successor y
     const long long per_tile = (long long)(p->mode == SDR_MODE_FM ? p->NT - 1 : p->NT) * p->R;
@@ -2407,6 +2460,16 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const int F = 30 - e2;                                 // |q| <= 2^30
         std::vector<long long> q(p->T);
         for (int i = 0; i < p->T; ++i) q[i] = std::llround(std::ldexp(d->taps[i], F));
+        // A tap that is not zero but vanishes here -- it rounds to zero (below 2^-31 of the largest: the
+        // numerical zeros of a windowed sinc where fc*t is an integer), or it has a lowest digit only
+        // (below 2^-24) and meets a sample of 0..255, whose one byte product is the one left out -- is the
+        // only way an output can be an exact 0 in this arithmetic and a tiny vector in the reference's
+        // (short of an exact cancellation over the whole window).  Only plans with such a tap pay for
+        // i8_zero_fix's look at their zeros.  (SDRHIP_ZFIX_ALWAYS=1 turns the look on for every plan:
+        // A/B measurements of its cost; it cannot change a result.)
+        static const bool zfix_always = std::getenv("SDRHIP_ZFIX_ALWAYS") != nullptr;
+        p->zfix = zfix_always;
+        for (int i = 0; i < p->T; ++i) p->zfix |= (std::llabs(q[i]) < 128 && d->taps[i] != 0.0);
         // Q11 samples, the kernel's sums start at weight 2^8 (int16) | Q7 samples, sums from weight 2^0 (int8)
         p->yscale = (float)std::ldexp(1.0, p->input == SDR_IN_I8_IQ ? -(F + 7) : -(F + 11) + 8);
         std::vector<int> rowsum((size_t)4 * 16, 0);            // [digit][row]
@@ -2454,8 +2517,6 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
     if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_atab8, at8.size() * sizeof(uint4));
     if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_atab8, at8.data(), at8.size() * sizeof(uint4), hipMemcpyHostToDevice);
-    if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_i8q, sdr_fir_plan::kQueueStreams * kI8QueueWords * sizeof(unsigned));
-    if (e == hipSuccess && p->mfma_i8) e = hipMemset(p->d_i8q, 0, sdr_fir_plan::kQueueStreams * kI8QueueWords * sizeof(unsigned));
     if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_btab8, bt8.size() * sizeof(uint4));
     if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_btab8, bt8.data(), bt8.size() * sizeof(uint4), hipMemcpyHostToDevice);
     if (e == hipSuccess && p->mfma_i8 && p->mode == SDR_MODE_FM) e = hipMalloc((void **)&p->d_ftaps, hf.size() * sizeof(float));
@@ -2485,6 +2546,7 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (p->d_atab8) (void)hipFree(p->d_atab8);
     if (p->d_btab8) (void)hipFree(p->d_btab8);
     if (p->d_i8q) (void)hipFree(p->d_i8q);
+    if (p->h_q_done) (void)hipHostFree(p->h_q_done);
     if (p->d_ftaps) (void)hipFree(p->d_ftaps);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);

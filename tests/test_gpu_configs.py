@@ -199,6 +199,33 @@ def test_headline_long_launch_dynamic_tile_order(sdr, oracle):
         b = o.to_numpy(np.float32, cnt + 8)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         del b
+    # the handle hipStreamPerThread ((hipStream_t)2) names a DIFFERENT stream in every host
+    # thread: two threads launching the plan on it at once must not share tile counters (such handles run
+    # the static order; counter blocks are keyed by hipStreamGetId)
+    import threading
+    per_thread = C.c_void_p(2)
+    t_outs = [sdr.DevBuf((cnt + 8) * 4) for _ in range(2)]
+    errs = []
+
+    def worker(o):
+        try:
+            assert plan.execute_dev(d_in, n, o, cnt, stream=per_thread.value) == cnt
+            assert hip.hipStreamSynchronize(per_thread) == 0
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(o,)) for o in t_outs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    sdr.sync()
+    for o in t_outs:
+        b = o.to_numpy(np.float32, cnt)
+        assert np.array_equal(a[:cnt].view(np.uint32), b.view(np.uint32))
+        del b
+    del t_outs
     # three short shards of the same stream (few tiles per workgroup: the static order)
     for ob in (0, cnt // 2 - 7, cnt - 300_000):
         oe = ob + 300_000

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Same-box A/B of two builds of libsdrhip: this tree's sdr_amd/libsdrhip.so against another .so (e.g. the
-previous round's build kept as sdr_amd/libsdrhip_r02.so), interleaved, one child process per
-measurement (a process binds one library).  usage: ab_libs.py <other.so> [rounds]
+"""Same-box A/B of builds of libsdrhip: this tree's sdr_amd/libsdrhip.so against other .so files (e.g. the
+previous round's build kept as sdr_amd/libsdrhip_r02.so, or experiment builds), interleaved, one child
+process per measurement (a process binds one library).  usage: ab_libs.py <a.so>[,<b.so>...] [rounds] [shapes]
 Each child times a list of FIR shapes (FM unless stated) and prints JSON; the parent tabulates."""
 import json
 import os
@@ -25,7 +25,8 @@ def child():
     sdr_amd.capi.synth_fm_i16_dev(d_in, n_max, fs=20e6, noise_lsb=8)
     d_out = sdr_amd.DevBuf((n_max // 4 + 64) * 8)
     out = []
-    for (l2, T, D, mode, inp, pipe) in SHAPES:
+    pick = [int(x) for x in os.environ.get("AB_SHAPES", "").split(",") if x] or list(range(len(SHAPES)))
+    for (l2, T, D, mode, inp, pipe) in [SHAPES[i] for i in pick]:
         n = 1 << l2
         h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
         p = sdr_amd.FirPlan(h, D, mode=mode, input=inp, pipeline=pipe)
@@ -43,12 +44,17 @@ def child():
 
 
 def main():
-    other = os.path.abspath(sys.argv[1])
+    """ab_libs.py <other.so>[,<other2.so>...] [rounds] [shape indices, comma separated]"""
+    others = [os.path.abspath(x) for x in sys.argv[1].split(",")]
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-    res = {"new": [], "old": []}
+    pick = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else list(range(len(SHAPES)))
+    libs = [("this", None)] + [(os.path.basename(o), o) for o in others]
+    res = {name: [] for name, _ in libs}
     for r in range(rounds):
-        for name, lib in (("old", other), ("new", None), ("new", None), ("old", other)):
+        order = libs if r % 2 == 0 else libs[::-1]
+        for name, lib in order + order[::-1]:
             env = dict(os.environ)
+            env["AB_SHAPES"] = ",".join(str(i) for i in pick)
             if lib:
                 env["SDRHIP_LIB"] = lib
             else:
@@ -59,12 +65,17 @@ def main():
                 sys.exit(cp.returncode or 1)
             line = [l for l in cp.stdout.splitlines() if l.startswith("AB ")][-1]
             res[name].append(json.loads(line[3:]))
-    print("shape (log2n T D mode input pipe)    kernel     old min / med      new min / med      new/old (min)")
-    for i, sh in enumerate(SHAPES):
-        o_min = min(r[i]["ms_min"] for r in res["old"]); n_min = min(r[i]["ms_min"] for r in res["new"])
-        o_med = sorted(r[i]["ms_med"] for r in res["old"])[len(res["old"]) // 2]
-        n_med = sorted(r[i]["ms_med"] for r in res["new"])[len(res["new"]) // 2]
-        print(f"{str(sh):36s} {res['new'][0][i]['kernel']:9s} {o_min:8.4f} {o_med:8.4f}   {n_min:8.4f} {n_med:8.4f}   {n_min / o_min:6.3f}")
+    print("ms per launch, min over runs (median of medians); shape = (log2n T D mode input pipe)")
+    print(f"{'shape':30s} {'kernel':9s} " + " ".join(f"{name[:22]:>22s}" for name, _ in libs))
+    for k, i in enumerate(pick):
+        cells = []
+        base = None
+        for name, _ in libs:
+            mn = min(r[k]["ms_min"] for r in res[name])
+            md = sorted(r[k]["ms_med"] for r in res[name])[len(res[name]) // 2]
+            base = base or mn
+            cells.append(f"{mn:8.4f} ({md:7.4f}) {mn / base:5.3f}")
+        print(f"{str(SHAPES[i]):30s} {res['this'][0][k]['kernel']:9s} " + " ".join(cells), flush=True)
 
 
 if __name__ == "__main__":

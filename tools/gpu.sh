@@ -9,7 +9,7 @@
 #   wip:<file>       one not-yet-collected test file (tests/wip_*.py)
 #   bench            bench.py with the driver's flags (--steps 20 --warmup 5)
 #   bench:<args>     bench.py with other arguments ("," separates arguments)
-#   ab:<lib>         headline + a few shapes, this build against sdr_amd/<lib> interleaved (tools/ab_libs.py)
+#   ab:<libs>[:rounds[:shapes]]  this build against other .so files (comma separated paths), interleaved (tools/ab_libs.py)
 #   py:<script,args> any script under tools/ ("," separates arguments)
 #   trace:<args>     rocprofv3 --kernel-trace --stats around bench.py <args>  -> <out>/trace_*
 #   pmc:<ctrs>:<args> one rocprofv3 --pmc pass (ctrs "+"-separated) around bench.py <args>
@@ -39,7 +39,7 @@ for step in "$@"; do
     bench)
         if [ -n "$arg" ]; then IFS=, read -ra a <<< "$arg"; run "bench_$i" 600 python3 -u bench.py "${a[@]}"
         else run "bench_$i" 600 python3 -u bench.py --steps 20 --warmup 5; fi ;;
-    ab)    run "ab_$i" 600 python3 -u tools/ab_libs.py "sdr_amd/$arg" ;;
+    ab)    IFS=: read -ra a <<< "$arg"; run "ab_$i" 900 python3 -u tools/ab_libs.py "${a[@]}" ;;
     py)    IFS=, read -ra a <<< "$arg"; run "py_$i" 900 python3 -u "tools/${a[0]}" "${a[@]:1}" ;;
     trace) IFS=, read -ra a <<< "$arg"
            run "trace_$i" 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_$i" -- python3 bench.py "${a[@]}" ;;

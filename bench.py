@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--chan-log2n", type=int, default=20)
     ap.add_argument("--prewarm-seconds", type=float, default=2.0,
                     help="upper bound of the clock-stabilising pre-warm that runs before --warmup (0 = off)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other BASELINE configs (channelizer, waterfall, APT chain) that the N = 1 stream run "
+                         "measures after the headline and reports under \"secondary\"")
+    ap.add_argument("--secondary-cpu-seconds", type=float, default=3.0, help="budget of each secondary config's CPU leg (0 = skip)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU: every rank uses device 0 and the collectives go "
                          "over gloo on host tensors (checks the sharded path; the numbers mean nothing)")
@@ -108,8 +112,43 @@ def cpu_all_cores(O, taps, D, budget_s):
             "sample": f"{threads} threads x {reps} passes over a 2^22-sample block each, {t:.1f} s"}
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` on its own: start N ranks (one process per GPU) through
+    torch.distributed.run as a child process and relay its output.  This process has not touched the
+    GPU (torch is not imported yet), and it starts a child rather than replacing itself."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def secondary(cpu_seconds):
+    """The other BASELINE configs on this GPU, once each, warm: kernel time (HIP events), roofline, spot
+    parity against the oracle and a bounded CPU baseline (tools/bench_configs.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as BC
+    out = {}
+    for name, fn in (("cfg3_channelizer", BC.cfg3), ("cfg4_waterfall", BC.cfg4), ("cfg5_apt_chain", BC.cfg5)):
+        t0 = time.perf_counter()
+        try:
+            r = fn(20, cpu_seconds)
+            r["wall_s"] = round(time.perf_counter() - t0, 1)
+            out[name] = r
+        except Exception as e:                      # the headline stands; say what failed
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     import torch
     import sdr_amd
     from oracle import oracle as O
@@ -129,7 +168,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
-    assert world == a.gpus or world == 1, (world, a.gpus)
+    assert world == a.gpus, f"--gpus {a.gpus} but the process group has {world} rank(s)"
     dev = torch.device("cuda", local)
     sdr_amd.init(local)
 
@@ -327,6 +366,11 @@ def main():
     if rank == 0:
         value = n_all * a.steps / dt / 1e6
         info = plan.info()
+        # the arithmetic the kernel that ran computes in (outputs are float32 either way)
+        arith = {"mfma_i8": "int8-split exact integer (int8 x int8 -> int32 matrix products of the samples' bytes and "
+                            "31-bit fixed-point taps), one float32 combination per output; float32 out",
+                 }.get(info["kernel"], "f32 (float32 taps and accumulation); float32 out")
+        info["arithmetic"] = arith
         # HBM bytes per launch from the PMC counters cannot be collected inside this process (they
         # need rocprofv3 around it): the figure comes from the tracked summary of the last counter run
         # of this same command and is labelled with its source
@@ -344,7 +388,7 @@ def main():
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if channels else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": arith, "data": "synthetic", "ranks_in_group": dist.get_world_size() if dist else 1,
             "config": ({"workload": f"FM channelizer, {a.channels} independent channels x 2^{a.chan_log2n} int16 IQ samples, "
                                     f"{T}-tap Hann LPF, decimate by {D}, discriminator (BASELINE configs[2]); "
                                     f"channels block-partitioned over the ranks, one batched launch per rank",
@@ -373,6 +417,10 @@ def main():
         if world == 1 and a.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(O, taps, D, a.cpu_seconds)
             line["cpu_baseline_all_cores"] = cpu_all_cores(O, taps, D, a.cpu_seconds / 3.0)
+        if world == 1 and not channels and not a.no_secondary:
+            del d_in, d_out
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary(a.secondary_cpu_seconds)
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

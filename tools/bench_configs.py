@@ -16,8 +16,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import sdr_amd  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+import parity_checks as PC  # noqa: E402  (the bars of include/sdr_hip.h as assertions)
 
 PEAK = 8000.0
 
@@ -36,16 +38,34 @@ def timed(fn, iters):
     return min(fn(iters) for _ in range(3))
 
 
+MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 matrix rate, 2x the ~2.5 PF bf16 figure (MI355X_MICROARCH.md, matrix cores)
+
+
 def line(name, samples, ms, bytes_per_sample, extra):
     gbs = bytes_per_sample * samples / (ms * 1e-3) / 1e9
     out = {"config": name, "Msamples_per_s": round(samples / ms / 1e3, 1), "kernel_ms": round(ms, 4),
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK, "unit": "GB/s",
                         "frac": round(gbs / PEAK, 4), "algorithmic_bytes_per_sample": bytes_per_sample}}
     out.update(extra)
-    print(json.dumps(out), flush=True)
+    return out
 
 
-def cfg3(iters):
+def cpu_leg(fn, samples, budget_s, kind, cores, what):
+    """time fn() (one pass over `samples` input samples on the host) for about budget_s seconds"""
+    import time
+    t0 = time.perf_counter()
+    fn()
+    t1 = time.perf_counter() - t0
+    reps = max(1, int(budget_s / max(t1, 1e-3)) - 1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    t = time.perf_counter() - t0
+    return {"value": round(samples * reps / t / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": kind,
+            "sample": f"{reps} passes over {what}, {t:.1f} s"}
+
+
+def cfg3(iters, cpu_seconds=0.0):
     n_ch, n, D, T = 1024, 1 << 20, 10, 64
     h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
     plan = sdr_amd.FirPlan(h, D, mode=sdr_amd.MODE_FM)
@@ -65,11 +85,21 @@ def cfg3(iters):
         worst = max(worst, float(np.abs(got - want).max()))
     assert worst <= 5e-6, worst
     ms = timed(lambda k: plan.time_dev(d_in, n, d_out, k, in_stride=n, n_channels=n_ch, out_stride=cnt), iters)
-    line("cfg3 channelizer 1024 x 2^20, 64 taps /10 FM", n_ch * n, ms, 4.0 + 4.0 / D,
-         {"parity_max_abs_err": worst, "kernel": plan.info()})
+    out = line("cfg3 channelizer 1024 x 2^20, 64 taps /10 FM (BASELINE configs[2])", n_ch * n, ms, 4.0 + 4.0 / D,
+               {"parity_max_abs_err": worst, "kernel": plan.info()})
+    if cpu_seconds > 0:
+        iq4 = d_in.to_numpy(np.int16, 2 * 4 * n)                # four channels
+        scale = 1.0 / (2.0 * np.pi)
+        if O.have_ref():
+            out["cpu_baseline"] = cpu_leg(lambda: [O.ref_time_chain_i16(iq4[2 * c * n: 2 * (c + 1) * n], D, h, O.MODE_FM, scale, 1) for c in range(4)],
+                                          4 * n, cpu_seconds, "reference", 1, "channels 0-3 (4 x 2^20 samples), the reference's own functions, float64")
+        else:
+            out["cpu_baseline"] = cpu_leg(lambda: [O.chain_i16(iq4[2 * c * n: 2 * (c + 1) * n], D, h, O.MODE_FM, scale) for c in range(4)],
+                                          4 * n, cpu_seconds, "port", 1, "channels 0-3 (4 x 2^20 samples), oracle port, float64")
+    return out
 
 
-def cfg4(iters):
+def cfg4(iters, cpu_seconds=0.0):
     n, nfft, hop = 1 << 28, 4096, 2048
     w = sdr_amd.window("blackman", nfft)
     plan = sdr_amd.FftPlan(nfft, hop, w)
@@ -88,11 +118,18 @@ def cfg4(iters):
         worst = max(worst, float(np.abs(lin - want_lin).max() / want_lin.max()))
     assert worst <= 1e-5, worst
     ms = timed(lambda k: plan.time_dev(d_in, n, d_out, k), iters)
-    line("cfg4 waterfall 4096-pt Blackman FFT -> dB, hop 2048, 2^28 samples", n, ms, 12.0,
-         {"parity_max_rel_power_err": worst, "frames": frames})
+    out = line("cfg4 waterfall 4096-pt Blackman FFT -> dB, hop 2048, 2^28 samples (BASELINE configs[3])", n, ms, 12.0,
+               {"parity_max_rel_power_err": worst, "frames": frames})
+    if cpu_seconds > 0:
+        m = 1 << 21
+        iqc = d_in.to_numpy(np.int16, 2 * m)
+        out["cpu_baseline"] = cpu_leg(lambda: O.fft_power_db_i16(iqc, nfft, hop, w), m, cpu_seconds, "port", 1,
+                                      "the first 2^21 samples (1023 frames), oracle port: float64 radix-2 FFT standing in for "
+                                      "af::fftInPlace (ArrayFire is not in the reference tree)")
+    return out
 
 
-def cfg5(iters):
+def cfg5(iters, cpu_seconds=0.0):
     n, D1, D2, T = 1 << 26, 10, 15, 511
     h1 = sdr_amd.create_fir_filter(T, 20800 / 62400.0 / 5, "hann")
     h2 = sdr_amd.create_fir_filter(T, 2400 / 62400.0, "hann")
@@ -113,17 +150,45 @@ def cfg5(iters):
     w9, w6 = O.apt_chain_i16(iq, D1, h1, fr, D2, h2)
     g6 = d_x6.to_numpy(np.float32, w6.size).astype(np.float64)
     g9 = d_x9.to_numpy(np.float32, w9.size).astype(np.float64)
+    # x6 by the discriminator's bars (start-up transient included), x9 against the reference's second
+    # stage on the GPU's own x6; the figure reported is the worst error past the transient
+    y4 = O.fir_decimate(O.unpack_scale_i16(iq), D1, h1)
+    PC.check_fm(g6.astype(np.float32), w6, y4, 1.0 / (2.0 * np.pi), "cfg5 x6")
+    PC.check_linear(g9, PC.apt_stage2(O, g6, fr, D2, h2), "cfg5 x9")
     s6 = T // D1 + 2
     s9 = s6 // D2 + 2 + T // D2
     worst = max(float(np.abs(g6 - w6)[s6:].max()), float(np.abs(g9 - w9)[s9:-T // D2 - 2].max()))
     assert worst <= 5e-6, worst
     ms1 = timed(lambda k: p1.time_dev(d_in, n, d_x6, k), iters)
     ms2 = timed(lambda k: p2.time_dev(d_x6, n6, d_x9, k), iters)
-    line("cfg5 APT 511 taps /10 FM -> mix -> 511 taps /15 envelope, 2^26 samples", n, ms1 + ms2,
-         4.0 + 4.0 / (D1 * D2), {"stage1_ms": round(ms1, 4), "stage2_ms": round(ms2, 4),
-                                 "fp32_flops_per_sample": round(4.0 * T / D1 + 4.0 * T / (D1 * D2), 1),
-                                 "achieved_tflops": round((4.0 * T / D1 + 4.0 * T / (D1 * D2)) * n / ((ms1 + ms2) * 1e-3) / 1e12, 2),
-                                 "parity_max_abs_err": worst, "stage1_kernel": p1.info(), "stage2_kernel": p2.info()})
+    ms = ms1 + ms2
+    out = line("cfg5 APT 511 taps /10 FM -> mix -> 511 taps /15 envelope, 2^26 samples (BASELINE configs[4])", n, ms,
+               4.0 + 4.0 / (D1 * D2), {"stage1_ms": round(ms1, 4), "stage2_ms": round(ms2, 4),
+                                       "parity_max_abs_err": worst, "stage1_kernel": p1.info(), "stage2_kernel": p2.info()})
+    # second ceiling: stage 1 runs on the int8 matrix pipe.  Issued work: per tile of 1020 stored outputs
+    # 8 column blocks x (k steps of the window) x 7 byte products, 16*16*64*2 operations each -- Toeplitz
+    # padding and the byte split included, so this is pipe occupancy, not useful arithmetic
+    if p1.info()["kernel"] == "mfma_i8":
+        nks = (((T - 1 + 3) // 4 * 4) + 15 * D1 + 1 + 63) // 64
+        tiles = (n6 + 1019) // 1020
+        ops = tiles * 8 * nks * 7 * 32768.0
+        tops = ops / (ms1 * 1e-3) / 1e12
+        hbm = out["roofline"]
+        mf = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8, issued)",
+              "frac": round(tops / MFMA_I8_PEAK_TOPS, 4), "of": "stage 1 alone", "mfma_per_tile": 8 * nks * 7}
+        out["roofline_hbm"] = hbm
+        out["roofline_mfma"] = mf
+        out["roofline"] = mf if mf["frac"] > hbm["frac"] else hbm       # the ceiling the chain is nearer to
+    if cpu_seconds > 0:
+        mc = 1 << 21
+        iqc = d_in.to_numpy(np.int16, 2 * mc)
+        if O.have_ref():
+            out["cpu_baseline"] = cpu_leg(lambda: O.ref_apt_chain_i16(iqc, D1, h1, fr, D2, h2), mc, cpu_seconds, "reference", 1,
+                                          "the first 2^21 samples, the reference's own functions (taps zero-padded to a multiple of D), float64")
+        else:
+            out["cpu_baseline"] = cpu_leg(lambda: O.apt_chain_i16(iqc, D1, h1, fr, D2, h2), mc, cpu_seconds, "port", 1,
+                                          "the first 2^21 samples, oracle port, float64")
+    return out
 
 
 def handoff(_iters):
@@ -168,5 +233,9 @@ def handoff(_iters):
 if __name__ == "__main__":
     sdr_amd.init(0)
     which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5", "handoff"]
+    cpu_s = float(os.environ.get("BENCH_CONFIGS_CPU_SECONDS", "0"))
     for w in which:
-        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5, "handoff": handoff}[w](20)
+        if w == "handoff":
+            handoff(20)
+        else:
+            print(json.dumps({"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[w](20, cpu_s)), flush=True)

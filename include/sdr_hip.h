@@ -206,6 +206,16 @@ typedef struct sdr_fir_desc {
                              persistent matrix kernel's ~13 us launch latency would outweigh its rate
                              (blocks below ~2^26 samples at 64 taps / 10, ~2^22 at 511 / 10).  The choice is made once, at plan creation: a plan's outputs do
                              not depend on how a stream is cut into launches. */
+    int n_mix_channels;   /* > 0: the channelizer (BASELINE config 3 as SURVEY 8 a7 words it) -- one NCO per
+                             channel in front of the filter: channel c of a batched launch is multiplied by
+                             exp(+j*2*pi*mix_fr_channels[c]*n), n = the sample's index in its stream
+                             (create_freq_rotation per channel, sdr_functions.h:63-74; frequency_shift,
+                             bladerf_apt_demod.cpp:476-495; the FM receiver's offset rotator
+                             exp(-2j*pi*(f_offset/fs)*n), bladerf_fm_demod.cpp:237-241, is the negative
+                             frequency).  An alternative to mix_fr (leave that 0); complex or integer input.
+                             Launches through sdr_fir_execute_channels_dev; the single-stream entry points
+                             (execute, range, host, stream hand-off) use channel 0's mixer. */
+    const double *mix_fr_channels; /* host, n_mix_channels doubles (cycles per sample; copied) */
 } sdr_fir_desc;
 
 /* Replaces the set-up half of polyphase_decimate (bladerf_apt_demod.cpp:249-279: argument
@@ -254,6 +264,18 @@ int sdr_fir_execute_range_dev(sdr_fir_plan *plan, const void *d_in, uint64_t in_
 int sdr_fir_execute_batched_dev(sdr_fir_plan *plan, const void *d_in, size_t n_in,
                                 size_t in_stride, size_t n_channels, void *d_out,
                                 size_t out_stride, void *stream);
+
+/* The channelizer launch: channels chan_first .. chan_first + n_channels - 1 of a plan created with
+ * per-channel mixers (sdr_fir_desc.n_mix_channels), one launch.  Channel k reads n_in samples at
+ * d_in + k*in_stride samples -- in_stride 0: every channel reads the SAME wideband buffer, the
+ * channelizer proper -- is mixed with its own NCO (mix_fr_channels[chan_first + k]), filtered,
+ * decimated and demodulated, and writes sdr_fir_out_count() outputs at d_out + k*out_stride elements.
+ * chan_first lets a rank that owns a block of the channels run it against the same plan.
+ * Replaces, per channel, create_freq_rotation / frequency_shift (sdr_functions.h:63-74,
+ * bladerf_apt_demod.cpp:476-495) + polyphase_decimate (:249-313) + polar_discriminator (:405-425). */
+int sdr_fir_execute_channels_dev(sdr_fir_plan *plan, const void *d_in, size_t n_in, size_t in_stride,
+                                 size_t chan_first, size_t n_channels, void *d_out, size_t out_stride,
+                                 void *stream);
 
 /* ---- a10: windowed FFT -> power in dB ------------------------------------------------------
  * Replaces bladerf_main_v1.cpp:183-196: complex<float>(I,Q)*(1/2048) -> af::fftInPlace(x, 1/N)

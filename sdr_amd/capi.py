@@ -33,7 +33,8 @@ class FirDesc(C.Structure):
     _fields_ = [("input", C.c_int), ("mode", C.c_int), ("decim", C.c_int), ("n_taps", C.c_int),
                 ("taps", C.POINTER(C.c_double)), ("scale", C.c_double), ("mix_fr", C.c_double),
                 ("outputs_per_lane", C.c_int), ("threads", C.c_int), ("pipeline", C.c_int),
-                ("count_rule", C.c_int), ("size_hint", C.c_longlong)]
+                ("count_rule", C.c_int), ("size_hint", C.c_longlong),
+                ("n_mix_channels", C.c_int), ("mix_fr_channels", C.POINTER(C.c_double))]
 
 
 # per-file compiler flags: the FFT's complex butterflies lose ~12 % when the SLP vectoriser pairs
@@ -185,12 +186,16 @@ class FirPlan:
     """sdr_fir_plan: FIR + decimate (+ mixer) + {IQ, FM discriminator, envelope}."""
 
     def __init__(self, taps, decim, mode=MODE_FM, input=IN_I16_IQ, scale=1.0 / (2.0 * np.pi),
-                 mix_fr=0.0, outputs_per_lane=0, threads=0, pipeline=0, count_rule=COUNT_FLOOR, size_hint=0):
+                 mix_fr=0.0, outputs_per_lane=0, threads=0, pipeline=0, count_rule=COUNT_FLOOR, size_hint=0,
+                 mix_fr_channels=None):
         self._taps = np.ascontiguousarray(taps, dtype=np.float64)
         self.mode, self.input, self.decim = mode, input, decim
+        self._chan = None if mix_fr_channels is None else np.ascontiguousarray(mix_fr_channels, dtype=np.float64)
         d = FirDesc(input, mode, decim, self._taps.size,
                     self._taps.ctypes.data_as(C.POINTER(C.c_double)), scale, mix_fr,
-                    outputs_per_lane, threads, pipeline, count_rule, int(size_hint))
+                    outputs_per_lane, threads, pipeline, count_rule, int(size_hint),
+                    0 if self._chan is None else self._chan.size,
+                    None if self._chan is None else self._chan.ctypes.data_as(C.POINTER(C.c_double)))
         self.h = C.c_void_p()
         check(lib().sdr_fir_plan_create(C.byref(d), C.byref(self.h)))
 
@@ -268,6 +273,16 @@ class FirPlan:
                                                 C.c_size_t(in_stride), C.c_size_t(n_channels),
                                                 _vp(d_out), C.c_size_t(out_stride),
                                                 C.c_void_p(stream or 0)))
+
+    def execute_channels_dev(self, d_in, n_in, in_stride, chan_first, n_channels, d_out, out_stride, stream=None):
+        """sdr_fir_execute_channels_dev: per-channel NCO + FIR + decimate + demod; in_stride 0 = one shared buffer"""
+        cnt = self.out_count(n_in)
+        if n_channels > 0:
+            self._fits("input", d_in, ((n_channels - 1) * in_stride + n_in) * self._in_bytes())
+            self._fits("output", d_out, ((n_channels - 1) * (out_stride or cnt) + cnt) * np.dtype(self.out_dtype).itemsize)
+        check(lib().sdr_fir_execute_channels_dev(self.h, _vp(d_in), C.c_size_t(n_in), C.c_size_t(in_stride),
+                                                 C.c_size_t(chan_first), C.c_size_t(n_channels), _vp(d_out),
+                                                 C.c_size_t(out_stride), C.c_void_p(stream or 0)))
 
     def time_dev(self, d_in, n_in, d_out, iters, in_stride=0, n_channels=1, out_stride=0,
                  stream=None):

@@ -83,6 +83,12 @@ struct FirGeom {
     int total_tiles;
     int ph_off;             // mixer: offset (floats) of the phasor tables behind the tap table
     int n_ph_hi;            // mixer: entries of the coarse table (tile offsets 0, 64, 128, ...)
+    // per-channel mixers (channelizer): channel c of the launch is plan channel chan_first + c; its NCO
+    // frequency is chan_fr[..] and its phasor tables start at chan_tab + (..) * chan_tab_stride float2
+    const double *chan_fr;  // nullptr: one mixer (mix_fr) for every channel
+    const float2 *chan_tab;
+    int chan_first;
+    int chan_tab_stride;
     int zfix;               // fir_mfma_i8_kernel, discriminator: some tap is below the fixed-point resolution (see i8_zero_fix)
 };
 
@@ -553,22 +559,44 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
     // Real input stays real in LDS (four samples per granule, half the LDS traffic of the walk) and
     // the mixer moves into the taps: y[m] = e^{j w m D} * sum_i (h[i] e^{-j w i}) x[mD - i], complex
     // taps built on the host, one rotation per output afterwards (none for the envelope).
-    const bool mixing = (IN != IN_REAL) && g.mix_fr != 0.0;
+    // Channelizer (g.chan_fr): every channel has its own frequency and its own pair of tables, and a
+    // persistent workgroup meets a different channel in nearly every tile.  The tables of the NEXT tile's
+    // channel are requested before that tile's samples (so waiting for them does not wait for the
+    // prefetch), kept in two registers per lane across the walk, and written to LDS behind it; the
+    // barrier at the top of the next round publishes them.
+    const bool chan = (IN != IN_REAL) && g.chan_fr != nullptr;
+    const bool mixing = (IN != IN_REAL) && (g.mix_fr != 0.0 || chan);
     float2 *ph_hi = (float2 *)(smem + (size_t)g.a_gran * 16 + (size_t)(NT + 2) * 8);
     float2 *ph_lo = ph_hi + g.n_ph_hi;
-    if (mixing) {
-        const float2 *src = (const float2 *)(gtab + g.ph_off);
-        for (int i = tid; i < g.n_ph_hi + 64; i += NT) ph_hi[i] = src[i];
-    }
+    const int n_tab = g.n_ph_hi + 64;            // channelizer plans: <= 2 * NT (plan creation)
+    auto tab_of = [&](int tile_no) {
+        const long long c = chan ? (long long)g.chan_first + tile_no / g.tiles_per_ch : 0;
+        return chan ? g.chan_tab + c * g.chan_tab_stride : (const float2 *)(gtab + g.ph_off);
+    };
+    float2 tab_a = make_float2(0.f, 0.f), tab_b = tab_a;
+    auto tab_request = [&](int tile_no) {
+        const float2 *src = tab_of(tile_no);
+        if (tid < n_tab) tab_a = src[tid];
+        if (tid + NT < n_tab) tab_b = src[tid + NT];
+    };
+    auto tab_publish = [&]() {
+        if (tid < n_tab) ph_hi[tid] = tab_a;
+        if (tid + NT < n_tab) ph_hi[tid + NT] = tab_b;
+    };
 
     int t = blockIdx.x;
+    if (mixing && t < g.total_tiles) {
+        const float2 *src = tab_of(t);
+        for (int i = tid; i < n_tab; i += NT) ph_hi[i] = src[i];
+    }
     if (t < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, t, g.per_tile));
     for (; t < g.total_tiles; t += gridDim.x) {
         const TileRef tr = tile_ref<IN>(g, in, t, g.per_tile);
         __syncthreads();                         // every lane has finished with the previous tile
         float2 B = make_float2(1.f, 0.f);
         if (mixing) {
-            const double ph = g.mix_fr * (double)tr.W0;
+            const double fr = chan ? g.chan_fr[g.chan_first + tr.ch] : g.mix_fr;
+            const double ph = fr * (double)tr.W0;
             sincospif(2.0f * (float)(ph - rint(ph)), &B.y, &B.x);
         }
 #pragma unroll
@@ -597,12 +625,14 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
         // request the next tile now: its HBM latency is covered by the walk below
         {
             const int tn = t + gridDim.x;
+            if (chan && tn < g.total_tiles) tab_request(tn);
             if (tn < g.total_tiles) fetch_tile(tile_ref<IN>(g, in, tn, g.per_tile));
         }
         __builtin_amdgcn_sched_barrier(0);
 
         float2 acc[R];
         walk<SPG, R, IN == IN_REAL>(g, (const uint4 *)tile, gtab, tid, acc);
+        if (chan && t + (int)gridDim.x < g.total_tiles) tab_publish();    // (nobody reads the tables before the next barrier)
 
         const long long m0 = tr.M0 + (long long)tid * R;
         if (IN == IN_REAL && g.mix_fr != 0.0 && g.mode != SDR_MODE_ENV) {
@@ -1846,6 +1876,11 @@ struct sdr_fir_plan {
     int stream_blocks = 0;  // persistent grid: CUs x resident workgroups per CU
     int ph_off = 0, n_ph_hi = 0;   // mixer phasor tables behind the tap table (float-tile kernel)
     float *d_gtab = nullptr;
+    // channelizer: per-channel NCO frequencies (double) and phasor tables (float2, tab_stride per channel)
+    int n_chan_mix = 0;
+    double *d_chan_fr = nullptr;
+    float2 *d_chan_tab = nullptr;
+    int chan_tab_stride = 0;
     // staging buffers for the *_host entry point
     void *d_in = nullptr, *d_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
@@ -2047,7 +2082,7 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
 // Enqueue one launch.  `in` points at stream sample index in_first of channel 0.
 int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resident,
            long long n_total, long long out_begin, long long out_end, long long in_stride,
-           size_t n_ch, void *out, long long out_stride, hipStream_t st)
+           size_t n_ch, void *out, long long out_stride, hipStream_t st, long long chan_first = 0)
 {
     if (out_end <= out_begin || n_ch == 0) return SDR_OK;
     if (n_ch > 65535) { sdr::set_error("n_channels > 65535"); return SDR_EINVAL; }
@@ -2083,6 +2118,14 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.swap_iq = (p->input == SDR_IN_I16_QI) ? 1 : 0;
     g.ph_off = p->ph_off; g.n_ph_hi = p->n_ph_hi;
     g.zfix = (p->mfma_i8 && p->mode == SDR_MODE_FM && p->zfix) ? 1 : 0;
+    g.chan_fr = nullptr; g.chan_tab = nullptr; g.chan_first = 0; g.chan_tab_stride = 0;
+    if (p->n_chan_mix > 0) {
+        if (chan_first < 0 || chan_first + (long long)n_ch > p->n_chan_mix) {
+            sdr::set_error("channels [%lld, %lld) but the plan has %d channel mixers", chan_first, chan_first + (long long)n_ch, p->n_chan_mix);
+            return SDR_EINVAL;
+        }
+        g.chan_fr = p->d_chan_fr; g.chan_tab = p->d_chan_tab; g.chan_first = (int)chan_first; g.chan_tab_stride = p->chan_tab_stride;
+    }
     g.scale = (float)p->scale;
     // with the discriminator a tile's last lane only supplies its neighbour's successor y
     const long long per_tile = (long long)(p->mode == SDR_MODE_FM ? p->NT - 1 : p->NT) * p->R;
@@ -2135,13 +2178,19 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
 
+    const bool chan_mix = d->n_mix_channels > 0;
+    if (d->n_mix_channels < 0 || (chan_mix && !d->mix_fr_channels)) { sdr::set_error("n_mix_channels without mix_fr_channels"); return SDR_EINVAL; }
+    if (chan_mix && d->mix_fr != 0.0) { sdr::set_error("mix_fr and mix_fr_channels are alternatives"); return SDR_EINVAL; }
+    if (chan_mix && d->input == SDR_IN_F32_REAL) { sdr::set_error("per-channel mixers need complex or integer input"); return SDR_EINVAL; }
+    if (chan_mix && d->n_mix_channels > 65535) { sdr::set_error("n_mix_channels > 65535"); return SDR_EINVAL; }
+
     sdr_fir_plan *p = new sdr_fir_plan();
     p->input = d->input; p->mode = d->mode; p->D = d->decim; p->T = d->n_taps;
     p->scale = d->scale; p->mix_fr = d->mix_fr; p->count_rule = d->count_rule;
     (void)hipGetDevice(&p->device);
-    const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0);
+    const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0 && !chan_mix);
     // the int8 matrix kernel also takes int8 sample pairs (one byte plane per component)
-    const bool i8_possible = raw_possible || (d->input == SDR_IN_I8_IQ && d->mix_fr == 0.0);
+    const bool i8_possible = raw_possible || (d->input == SDR_IN_I8_IQ && d->mix_fr == 0.0 && !chan_mix);
     if ((d->pipeline == 1 || d->pipeline == 3 || d->pipeline == 4) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3 and 4 need int16 input without mixer"); return SDR_EINVAL; }
     if (d->pipeline == 5 && !i8_possible) { delete p; sdr::set_error("pipeline 5 needs int16 or int8 input without mixer"); return SDR_EINVAL; }
     const bool ksplit_possible = d->input == SDR_IN_F32_REAL && d->mode != SDR_MODE_FM;
@@ -2348,8 +2397,10 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                 const int NT = NTs[ni];
                 if (d->threads && d->threads != NT) continue;
                 Geometry gm;
-                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false, d->mix_fr != 0.0 && spg == 2)) break;
+                if (!make_geometry(p->T, p->D, R, NT, spg, !raw, &gm, false, (d->mix_fr != 0.0 || chan_mix) && spg == 2)) break;
                 if (gm.n_inst > kSlots && pass == 0) continue;
+                // channelizer: a lane carries at most two table entries across the walk (fir_stream_kernel)
+                if (chan_mix && ph_hi_entries(gm.s_gran) + 64 > 2 * NT) continue;
                 const bool forced = d->threads != 0;
                 // automatic choice: float tiles <= 80 KB (two workgroups per CU; three below 53 KB)
                 const int budget = (forced || ni == 2 || pass == 1) ? 160 * 1024 : 80 * 1024;
@@ -2419,19 +2470,33 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             gt[2 * (j * p->R + r)] = (float)(d->taps[i] * std::cos(2.0 * M_PI * f));
             gt[2 * (j * p->R + r) + 1] = (float)(-d->taps[i] * std::sin(2.0 * M_PI * f));
         }
+    // mixer phasor tables (see fir_stream_kernel), phases reduced in double: HI[j] = the phasor of offset
+    // 64*j, LO[i] of offset i
+    auto phasor_tables = [](double fr, int n_hi, std::vector<float> &dst) {
+        auto phasor = [&](long long i) {
+            const double ph = fr * (double)i;
+            const double f = ph - std::rint(ph);
+            dst.push_back((float)std::cos(2.0 * M_PI * f));
+            dst.push_back((float)std::sin(2.0 * M_PI * f));
+        };
+        for (int j = 0; j < n_hi; ++j) phasor(64LL * j);
+        for (int i = 0; i < 64; ++i) phasor(i);
+    };
     if (!p->raw && p->mix_fr != 0.0 && !real_tile) {
-        // mixer phasor tables (see fir_stream_kernel), phases reduced in double
         while (gt.size() % 4) gt.push_back(0.0f);                 // 16-byte aligned
         p->ph_off = (int)gt.size();
         p->n_ph_hi = ph_hi_entries(p->s_gran);
-        auto phasor = [&](long long i) {
-            const double ph = p->mix_fr * (double)i;
-            const double f = ph - std::rint(ph);
-            gt.push_back((float)std::cos(2.0 * M_PI * f));
-            gt.push_back((float)std::sin(2.0 * M_PI * f));
-        };
-        for (int j = 0; j < p->n_ph_hi; ++j) phasor(64LL * j);
-        for (int i = 0; i < 64; ++i) phasor(i);
+        phasor_tables(p->mix_fr, p->n_ph_hi, gt);
+    }
+    std::vector<float> chan_tab;
+    if (chan_mix) {
+        // the channelizer: one pair of tables per channel (frequency_shift / create_freq_rotation per
+        // channel, bladerf_apt_demod.cpp:476-495, sdr_functions.h:63-74), ~1 KB each
+        p->n_ph_hi = ph_hi_entries(p->s_gran);
+        p->chan_tab_stride = p->n_ph_hi + 64;
+        p->n_chan_mix = d->n_mix_channels;
+        chan_tab.reserve((size_t)p->n_chan_mix * p->chan_tab_stride * 2);
+        for (int c = 0; c < p->n_chan_mix; ++c) phasor_tables(d->mix_fr_channels[c], p->n_ph_hi, chan_tab);
     }
     std::vector<float4> at;
     if (p->mfma) {
@@ -2524,6 +2589,10 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (e == hipSuccess && p->mfma) e = hipMalloc((void **)&p->d_atab, at.size() * sizeof(float4));
     if (e == hipSuccess && p->mfma) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_gtab, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && chan_mix) e = hipMalloc((void **)&p->d_chan_tab, chan_tab.size() * sizeof(float));
+    if (e == hipSuccess && chan_mix) e = hipMemcpy(p->d_chan_tab, chan_tab.data(), chan_tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && chan_mix) e = hipMalloc((void **)&p->d_chan_fr, (size_t)p->n_chan_mix * sizeof(double));
+    if (e == hipSuccess && chan_mix) e = hipMemcpy(p->d_chan_fr, d->mix_fr_channels, (size_t)p->n_chan_mix * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         sdr_fir_plan_destroy(p);
         return sdr::hip_fail(e, "plan upload");
@@ -2548,6 +2617,8 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (p->d_i8q) (void)hipFree(p->d_i8q);
     if (p->h_q_done) (void)hipHostFree(p->h_q_done);
     if (p->d_ftaps) (void)hipFree(p->d_ftaps);
+    if (p->d_chan_tab) (void)hipFree(p->d_chan_tab);
+    if (p->d_chan_fr) (void)hipFree(p->d_chan_fr);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     delete p;
@@ -2628,6 +2699,19 @@ extern "C" int sdr_fir_execute_batched_dev(sdr_fir_plan *p, const void *d_in, si
     if (n_channels > 1 && (in_stride < n_in || out_stride < (size_t)cnt)) { sdr::set_error("channel stride smaller than channel length"); return SDR_EINVAL; }
     return launch(p, d_in, 0, (long long)n_in, (long long)n_in, 0, cnt, (long long)in_stride,
                   n_channels, d_out, (long long)out_stride, (hipStream_t)stream);
+}
+
+extern "C" int sdr_fir_execute_channels_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, size_t in_stride,
+                                            size_t chan_first, size_t n_channels, void *d_out, size_t out_stride,
+                                            void *stream)
+{
+    if (!p || !d_in || !d_out) { sdr::set_error("null argument"); return SDR_EINVAL; }
+    if (p->n_chan_mix <= 0) { sdr::set_error("the plan has no per-channel mixers (sdr_fir_desc.n_mix_channels)"); return SDR_EINVAL; }
+    const long long cnt = out_count(p, (long long)n_in);
+    // in_stride 0: every channel reads the same wideband buffer
+    if (n_channels > 1 && ((in_stride != 0 && in_stride < n_in) || out_stride < (size_t)cnt)) { sdr::set_error("channel stride smaller than channel length"); return SDR_EINVAL; }
+    return launch(p, d_in, 0, (long long)n_in, (long long)n_in, 0, cnt, (long long)in_stride,
+                  n_channels, d_out, (long long)out_stride, (hipStream_t)stream, (long long)chan_first);
 }
 
 extern "C" int sdr_fir_execute_host(sdr_fir_plan *p, const void *in, size_t n_in, void *out,

@@ -1076,6 +1076,94 @@ def test_matrix_kernel_zero_runs(sdr, oracle, T, D, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,T,D", [("i16", 64, 10), ("i16", 101, 5), ("cf32", 64, 10), ("i8", 64, 10), ("qi", 200, 8),
+                                      ("i16", 511, 10)])
+def test_channelizer_per_channel_mixers(sdr, oracle, kind, T, D):
+    """The channelizer as SURVEY 8 a7 words BASELINE config 3: one NCO per channel in front of the filter
+    (create_freq_rotation / frequency_shift per channel, sdr_functions.h:63-74, bladerf_apt_demod.cpp:476-495;
+    negative frequencies = the FM receiver's offset rotator, bladerf_fm_demod.cpp:237-241), then
+    polyphase_decimate and the discriminator / envelope, all channels in one launch.  Channels read ONE
+    shared wideband buffer (in_stride 0) or a buffer each; every channel against the oracle's
+    frequency_shift -> fir_decimate -> demod on the same samples; a block of the channels launched with
+    chan_first (a rank's shard) equals the same channels of the whole launch bit for bit."""
+    rng = np.random.default_rng(T * 13 + D)
+    n_ch, n = 11, 60_000 + 7 * D + 3
+    frs = np.concatenate(([0.0, 0.25, -0.5], rng.uniform(-0.5, 0.5, n_ch - 3)))
+    h = oracle.create_fir_filter(T, 0.4 / D, "hann")
+    # wideband test signal: an FM carrier at every channel's frequency (so that each channel, once mixed to
+    # zero, holds a constant-envelope FM signal) plus noise
+    t = np.arange(n)
+    x = np.zeros(n, np.complex128)
+    for c in range(n_ch):
+        ph = 2 * np.pi * (-frs[c] * t + 0.003 * np.sin(2 * np.pi * (1e-3 + 2e-4 * c) * t) / (1e-3 + 2e-4 * c) / (2 * np.pi) * 2 * np.pi)
+        x += np.exp(1j * ph)
+    x *= 0.9 / n_ch
+    if kind in ("i16", "qi"):
+        iq = np.empty(2 * n, np.int16)
+        iq[0::2] = np.rint(2047 * x.real) + rng.integers(-3, 4, n)
+        iq[1::2] = np.rint(2047 * x.imag) + rng.integers(-3, 4, n)
+        xs = oracle.unpack_scale_i16(iq)
+        raw, inp, esz = (iq, sdr.IN_I16_IQ, 4) if kind == "i16" else (iq.reshape(-1, 2)[:, ::-1].reshape(-1).copy(), sdr.IN_I16_QI, 4)
+    elif kind == "i8":
+        raw = np.empty(2 * n, np.int8)
+        raw[0::2] = np.clip(np.rint(127 * x.real) + rng.integers(-1, 2, n), -128, 127)
+        raw[1::2] = np.clip(np.rint(127 * x.imag) + rng.integers(-1, 2, n), -128, 127)
+        xs, inp, esz = oracle.unpack_scale_i8(raw), sdr.IN_I8_IQ, 2
+    else:
+        raw = x.astype(np.complex64)
+        xs, inp, esz = raw.astype(np.complex128), sdr.IN_CF32, 8
+    ys = [oracle.fir_decimate(oracle.frequency_shift(xs, frs[c]), D, h) for c in range(n_ch)]
+    d_in = sdr.DevBuf.from_numpy(raw)
+    for mode, dt, eb in ((sdr.MODE_FM, np.float32, 4), (sdr.MODE_ENV, np.float32, 4), (sdr.MODE_IQ, np.complex64, 8)):
+        plan = sdr.FirPlan(h, D, mode=mode, input=inp, mix_fr_channels=frs)
+        cnt = plan.out_count(n)
+        stride = cnt + 3
+        SENT = 0x7FC0DEAD
+        d_out = sdr.DevBuf.from_numpy(np.full(stride * n_ch * (eb // 4), SENT, np.uint32))
+        plan.execute_channels_dev(d_in, n, 0, 0, n_ch, d_out, stride)          # one shared wideband buffer
+        sdr.sync()
+        out = d_out.to_numpy(dt, stride * n_ch).reshape(n_ch, stride)
+        assert (out[:, cnt:].view(np.uint32) == SENT).all()
+        for c in range(n_ch):
+            tag = f"channelizer {kind} {T}/{D} mode {mode} channel {c} fr {frs[c]:+.4f}"
+            if mode == sdr.MODE_FM:
+                check_fm(out[c, :cnt], oracle.polar_discriminator(ys[c], 1 / TWO_PI), ys[c], 1 / TWO_PI, tag)
+            elif mode == sdr.MODE_ENV:
+                check_linear(out[c, :cnt], np.abs(ys[c]), tag)
+            else:
+                check_linear(out[c, :cnt], ys[c], tag)
+        # a rank's block of the channels: channels 4..8 launched on their own with chan_first = 4
+        d_blk = sdr.DevBuf.from_numpy(np.full(stride * 5 * (eb // 4), SENT, np.uint32))
+        plan.execute_channels_dev(d_in, n, 0, 4, 5, d_blk, stride)
+        sdr.sync()
+        blk = d_blk.to_numpy(dt, stride * 5).reshape(5, stride)
+        assert np.array_equal(blk[:, :cnt].view(np.uint32), out[4:9, :cnt].view(np.uint32))
+        # a buffer per channel (in_stride = n + 5): channel c's buffer holds the wideband signal delayed by c samples
+        if mode == sdr.MODE_ENV:
+            sin = n + 5
+            per = 2 if kind != "cf32" else 1
+            buf = np.zeros(sin * 3 * per, raw.dtype)
+            for k in range(3):
+                buf[(k * sin + k) * per: (k * sin + n) * per] = raw[: (n - k) * per]
+            d_sep = sdr.DevBuf.from_numpy(buf)
+            d_o3 = sdr.DevBuf(stride * 3 * eb)
+            plan.execute_channels_dev(d_sep, n, sin, 5, 3, d_o3, stride)
+            sdr.sync()
+            o3 = d_o3.to_numpy(dt, stride * 3).reshape(3, stride)
+            for k in range(3):
+                xk = np.concatenate((np.zeros(k, np.complex128), xs[: n - k]))
+                yk = oracle.fir_decimate(oracle.frequency_shift(xk, frs[5 + k]), D, h)
+                check_linear(o3[k, :cnt], np.abs(yk), f"separate buffers, channel {5 + k}")
+        # argument errors: channels beyond the plan's mixers; a plan without mixers
+        with pytest.raises(sdr.SdrError):
+            plan.execute_channels_dev(d_in, n, 0, 8, 4, d_out, stride)
+    with pytest.raises(sdr.SdrError):
+        sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp).execute_channels_dev(d_in, n, 0, 0, 1, d_out, stride)
+    with pytest.raises(sdr.SdrError):
+        sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp, mix_fr=0.1, mix_fr_channels=frs)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_fft4096_kernel_variants(sdr, oracle, variant):
     """The 4096-point / hop-2048 waterfall has four kernels (sdr_fft_plan_set_variant): one frame per

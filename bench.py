@@ -134,7 +134,17 @@ def secondary(cpu_seconds):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_configs as BC
     out = {}
-    for name, fn in (("cfg3_channelizer", BC.cfg3), ("cfg4_waterfall", BC.cfg4), ("cfg5_apt_chain", BC.cfg5)):
+    import bench_channelizer as BCH
+
+    def nco(_iters, _cpu):
+        return BCH.run("cfg3 with one NCO per channel: 1024 separate 2^20-sample streams, per-channel mixer -> 64 taps /10 -> FM "
+                       "(sdr_fir_execute_channels_dev; SURVEY 8 a7)", 1 << 20, False, emit=False)
+
+    def nco_shared(_iters, _cpu):
+        return BCH.run("channelizer proper: 1024 NCOs on ONE shared 2^22-sample wideband stream", 1 << 22, True, emit=False)
+
+    for name, fn in (("cfg3_channelizer", BC.cfg3), ("cfg3_channelizer_per_channel_nco", nco), ("channelizer_shared_wideband_input", nco_shared),
+                     ("cfg4_waterfall", BC.cfg4), ("cfg5_apt_chain", BC.cfg5)):
         t0 = time.perf_counter()
         try:
             r = fn(20, cpu_seconds)

@@ -86,7 +86,8 @@ struct FirGeom {
     // per-channel mixers (channelizer): channel c of the launch is plan channel chan_first + c; its NCO
     // frequency is chan_fr[..] and its phasor tables start at chan_tab + (..) * chan_tab_stride float2
     const double *chan_fr;  // nullptr: one mixer (mix_fr) for every channel
-    const float2 *chan_tab;
+    const float2 *chan_tab; // float-tile kernel: phasor tables; complex-tap matrix kernel: chan_e, one float2
+                            // per channel, exp(j*2*pi*fr*D) (what one output step turns the mixer by)
     int chan_first;
     int chan_tab_stride;
     int zfix;               // fir_mfma_i8_kernel, discriminator: some tap is below the fixed-point resolution (see i8_zero_fix)
@@ -1324,6 +1325,8 @@ struct I8Chan {
     const void *src;
     const float *taps;
     long long lo_valid, hi_valid;
+    double fr;              // channelizer plans: the channel's NCO frequency (the sample is mixed as the reference
+                            // mixes it, phase = fr * n reduced in double, bladerf_apt_demod.cpp:488); else 0
     int D, T, swap_iq;
 };
 
@@ -1346,7 +1349,8 @@ __device__ __forceinline__ float2 i8_y_f32(const I8Chan &c, long long m, int lan
         const float h = c.taps[k];
         const long long s = n0 - k;
         if (s >= c.lo_valid && s < c.hi_valid) {
-            const float2 x = sample(s);
+            float2 x = sample(s);
+            if (c.fr != 0.0) x = mix(x, c.fr, s);
             a.x = __fmaf_rn(h, x.x, a.x);
             a.y = __fmaf_rn(h, x.y, a.y);
         }
@@ -1361,6 +1365,7 @@ __device__ __forceinline__ I8Chan i8_chan(const uint32_t *__restrict__ in, const
     c.src = (const unsigned char *)in + (S8 ? 2 : 4) * (ch * g.in_stride);
     c.taps = taps;
     c.lo_valid = g.lo_valid; c.hi_valid = g.hi_valid;
+    c.fr = g.chan_fr ? g.chan_fr[g.chan_first + ch] : 0.0;
     c.D = g.D; c.T = g.T; c.swap_iq = g.swap_iq;
     return c;
 }
@@ -1394,11 +1399,18 @@ __device__ __forceinline__ void i8_startup_fm_output(const uint32_t *__restrict_
 // RH*F) and their successor y[m0 + RH] (slot RH).  Stored outputs: store_from <= j < out_end.
 // A real function, not inlined: it runs once in a blue moon, and inlined its registers (and the scalar
 // registers of its loops) crowd the matrix waves' tap digits -- 75 scalar spills in the headline kernel.
-template <int RH> struct I8Ys { float2 y[RH + 1]; };
+// Complex taps (CPX, the channelizer): the matrix pipe yields z[m] = sum_i (h[i] e^{-jwi}) x[mD - i], i.e.
+// y[m] without the mixer's phasor e^{jwmD} of the output's own sample, and the fast path turns the
+// discriminator's product by the constant e^{jwD} instead of turning every y.  A lane that holds a flagged
+// zero leaves that shortcut: its slots come back as the reference's y -- recomputed (mixed sample by sample,
+// as the reference mixes) where flagged, turned by their own phasor elsewhere -- and ydom tells the caller
+// to take the plain discriminator for that lane.
+template <int RH> struct I8Ys { float2 y[RH + 1]; int ydom; };
 
-template <int RH, bool S8>
+template <int RH, bool S8, bool CPX>
 __device__ __noinline__ I8Ys<RH> i8_zero_fix(I8Chan c, long long m0, long long store_from, long long out_end, I8Ys<RH> v)
 {
+    v.ydom = 0;
     const int lane = threadIdx.x & 63;
     bool flag[RH + 1];
     bool any = false;
@@ -1432,6 +1444,19 @@ __device__ __noinline__ I8Ys<RH> i8_zero_fix(I8Chan c, long long m0, long long s
             todo &= todo - 1;
             const float2 yv = i8_y_f32<S8>(c, m_first + (long long)RH * l + r, lane);
             if (lane == l) v.y[r] = yv;
+        }
+    }
+    if constexpr (CPX) {
+        if (any) {
+            v.ydom = 1;
+#pragma unroll
+            for (int r = 0; r <= RH; ++r) {
+                if (flag[r]) continue;                     // recomputed above: already the reference's y
+                const double ph = c.fr * (double)((m0 + r) * c.D);
+                float2 P;
+                sincospif(2.0f * (float)(ph - rint(ph)), &P.y, &P.x);
+                v.y[r] = cmulf(v.y[r], P);
+            }
         }
     }
     return v;
@@ -1498,7 +1523,7 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
 #pragma unroll
             for (int r = 0; r < RH; ++r) v.y[r] = y[r];
             v.y[RH] = ynext;
-            v = i8_zero_fix<RH, S8>(i8_chan<S8>(in, ftaps, g, ch), M0 + (long long)o0, g.store_from,
+            v = i8_zero_fix<RH, S8, false>(i8_chan<S8>(in, ftaps, g, ch), M0 + (long long)o0, g.store_from,
                                     tile_end < g.out_end ? tile_end : g.out_end, v);
             bool changed = v.y[RH].x != ynext.x || v.y[RH].y != ynext.y;
 #pragma unroll
@@ -1509,13 +1534,103 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
     }
 }
 
+// Finishing for complex taps (the channelizer; see I8Ys): ybuf holds z[m], the filter output without the
+// mixer's phasor of its own sample, y[m] = e^{jw mD} z[m].
+//   envelope       |y| = |z|: nothing to do
+//   discriminator  y[m+1] conj(y[m]) = e^{jwD} z[m+1] conj(z[m]): one constant turn E = e^{jwD} per channel
+//                  on the product (four multiply-adds per output) instead of a phasor per y; the product
+//                  of two exact zeros stays (+0, +0) (the turn's -0 is washed out by adding +0); a lane with
+//                  ONE exact zero goes through i8_zero_fix, which brings back the reference's y
+//   IQ             y itself is the output: the lane's first phasor from its phase (reduced in double), the
+//                  following ones by E
+template <int RH, int NCB, bool S8>
+__device__ __forceinline__ void i8_finish_cpx(const FirGeom &g, void *__restrict__ outv, const float *ybuf, int par, int F, int t,
+                                              const uint32_t *__restrict__ in, const float *__restrict__ ftaps)
+{
+    constexpr int TILE = 128 * NCB;
+    const int o0 = RH * F, o2 = o0 + RH < TILE ? o0 + RH : TILE - 1;
+    const float *pa = ybuf + par * NCB * (4 * kI8PartSlots) + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
+    const float *pb = ybuf + par * NCB * (4 * kI8PartSlots) + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
+    const int ch = i8_tile_channel(g, t);
+    const long long M0 = g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile;
+    const long long m0 = M0 + (long long)o0;
+    const long long tile_end = M0 + g.per_tile;
+    const long long out_end = tile_end < g.out_end ? tile_end : g.out_end;
+    const float2 E = g.chan_tab[g.chan_first + ch];
+    float2 y[RH], ynext;
+    if constexpr (RH == 4) {
+        const float4 qi = *(const float4 *)pa, qq = *(const float4 *)(pa + 4 * 33);
+        y[0] = make_float2(qi.x, qq.x); y[1] = make_float2(qi.y, qq.y);
+        y[2] = make_float2(qi.z, qq.z); y[3] = make_float2(qi.w, qq.w);
+    } else {
+        static_assert(RH == 2, "complex-tap tiles have 1024 outputs");
+        const float2 qi = *(const float2 *)pa, qq = *(const float2 *)(pa + 4 * 33);
+        y[0] = make_float2(qi.x, qq.x); y[1] = make_float2(qi.y, qq.y);
+    }
+    ynext = make_float2(pb[0], pb[4 * 33]);
+    if (g.mode == SDR_MODE_ENV) {
+        float v[RH];
+#pragma unroll
+        for (int r = 0; r < RH; ++r) v[r] = sqrtf(__fmaf_rn(y[r].x, y[r].x, y[r].y * y[r].y));
+        store_values<RH>(g, outv, ch, m0, v, out_end);
+        return;
+    }
+    if (g.mode == SDR_MODE_IQ) {
+        const double ph = g.chan_fr[g.chan_first + ch] * (double)(m0 * g.D);
+        float2 P;
+        sincospif(2.0f * (float)(ph - rint(ph)), &P.y, &P.x);
+        float2 *dst = (float2 *)outv + (long long)ch * g.out_stride + (m0 - g.out_begin);
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+            const float2 o = cmulf(y[r], P);
+            if (m0 + r >= g.store_from && m0 + r < out_end) nt_store((float *)(dst + r), o.x, o.y);
+            P = cmulf(P, E);
+        }
+        return;
+    }
+    // discriminator
+    auto turned = [&](float2 y1, float2 y0) {
+        const float a = y1.x, b = y1.y, c = y0.x, e = -y0.y;
+        const float re = __fmaf_rn(a, c, -(b * e)), im = __fmaf_rn(a, e, b * c);
+        const float tr = __fmaf_rn(re, E.x, -(im * E.y)) + 0.0f, ti = __fmaf_rn(re, E.y, im * E.x) + 0.0f;
+        return g.scale * atan2_finite(ti, tr);
+    };
+    float v[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) v[r] = turned(r + 1 < RH ? y[r + 1] : ynext, y[r]);
+    store_values<RH>(g, outv, ch, m0, v, out_end);
+    unsigned mn = __float_as_uint(ynext.x) | __float_as_uint(ynext.y);
+#pragma unroll
+    for (int r = 0; r < RH; ++r) mn = min(mn, __float_as_uint(y[r].x) | __float_as_uint(y[r].y));
+    if (__builtin_expect(__ballot(mn == 0u) != 0ULL, 0)) {
+        I8Ys<RH> w;
+#pragma unroll
+        for (int r = 0; r < RH; ++r) w.y[r] = y[r];
+        w.y[RH] = ynext;
+        w = i8_zero_fix<RH, S8, true>(i8_chan<S8>(in, ftaps, g, ch), m0, g.store_from, out_end, w);
+        if (__ballot(w.ydom != 0) != 0ULL) {
+#pragma unroll
+            for (int r = 0; r < RH; ++r)
+                v[r] = w.ydom ? discriminate(w.y[r + 1], w.y[r], g.scale) : v[r];
+            store_values<RH>(g, outv, ch, m0, v, out_end);
+        }
+    }
+}
+
 // NS = k steps of the window, rounded up to a multiple of four (steps past the window carry zero taps
 // and are skipped; the staged tile covers NS steps, so no sample read leaves it).
 // PRE = octets (8 samples) per helper lane and tile: 256 * PRE * 8 samples cover the staged tile.
 // S8 = int8 sample pairs (SDR_IN_I8_IQ): one byte plane per component, four byte products per step
 // (every tap digit with the sample byte; weights 2^0 .. 2^24, no low-byte bias), one 16-byte load per octet.
 // DYN = tiles are drawn from the per-XCD counters at qctr (see i8_draw) instead of the static order.
-template <int NS, int NCB, int PRE, bool S8, bool DYN>
+// CPX = complex taps, one set per channel (the channelizer: the per-channel mixer folded into the taps,
+// g[i] = h[i] e^{-jwi}; see i8_finish_cpx): the digits of Re g and Im g are two A operands, each step runs
+// its byte products twice into two sets of accumulators, and the combination subtracts / adds the
+// neighbouring column's "imaginary" sums (real output = Gr*Xi - Gi*Xq, imaginary = Gr*Xq + Gi*Xi; the I
+// and Q columns of a group sit in adjacent lanes).  A workgroup takes a CONTIGUOUS run of tiles, so it
+// changes channel -- and reloads 32 KB of digits -- a handful of times per launch.  Windows of up to
+// four steps (NS = 4), tiles of 1024 outputs, static order.
+template <int NS, int NCB, int PRE, bool S8, bool DYN, bool CPX = false>
 __global__ void __launch_bounds__(512, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
@@ -1539,9 +1654,15 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     int *tq = (int *)(smem + 2 * buf_bytes + 2 * NCB * kI8PartSlots * 16 + (NS > 8 ? kI8MaxSteps * 1024 : 0));
     unsigned q_drawn = 0;                                      // (lane 0 of wave 0) the place drawn in the previous phase
     unsigned G = gridDim.x, xcd = blockIdx.x & 7;
-    int slot0 = i8_tile_index(0);
+    static_assert(!CPX || (NS == 4 && NCB == 8 && !DYN), "complex taps: four steps, 1024-output tiles, static order");
+    // static order: tile n of this workgroup is n * tstep + slot0 -- every G-th tile, or (complex taps) a
+    // contiguous run of ceil(total / G) tiles
+    const int run = (g.total_tiles + (int)G - 1) / (int)G;
+    const int tstep = CPX ? 1 : (int)G;
+    int slot0 = CPX ? (int)blockIdx.x * run : i8_tile_index(0);
     int tq_snap = 0;
-    const int n_t = (g.total_tiles - slot0 + (int)G - 1) / (int)G;   // static order: this workgroup's tiles ...
+    const int n_t = CPX ? max(0, min(run, g.total_tiles - slot0))
+                        : (g.total_tiles - slot0 + (int)G - 1) / (int)G;   // static order: this workgroup's tiles ...
     // ... and phases.  (Dynamic order: an upper bound, left early: hipcc schedules the loops with a trip
     // count visibly better than the same loops without one -- 7 % on short phases.)
     const int n_ph_s = DYN ? (g.total_tiles + 4) & ~1 : (n_t + 3) & ~1;
@@ -1558,7 +1679,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     }
     auto tile_of = [&](int n) -> int {                         // n in p-2 .. p+2
         if constexpr (DYN) return n < 0 ? -1 : __builtin_amdgcn_readlane(tq_snap, n & 7);
-        else return (n >= 0 && n < n_t) ? n * (int)G + slot0 : -1;
+        else return (n >= 0 && n < n_t) ? n * tstep + slot0 : -1;
     };
     // who finishes: 0 the matrix waves, 1 the helper waves, 2 both (one half of the tile each; see the matrix waves)
     constexpr int FIN = (NCB == 8 && PRE <= (S8 ? 6 : 4)) ? 2 : 0;
@@ -1576,15 +1697,26 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // would be 192 registers and leave no room for the epilogue: the lowest digit, which only one of
         // the seven products reads, then lives in LDS and is fetched with the samples (144 registers).
         constexpr bool A0_LDS = NS > 8;
-        i32x4 a[NS][4];
+        constexpr int NP = CPX ? 2 : 1;                        // tap parts: real only | real, imaginary
+        i32x4 a[NS][NP][4];
         uint4 *a0lds = (uint4 *)(ybuf + 2 * NCB * kI8PartSlots);
+        int ch_loaded = CPX ? -1 : 0;                          // complex taps: the channel whose digits are resident
+        if constexpr (!CPX) {
 #pragma unroll
-        for (int ks = 0; ks < NS; ++ks)
+            for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                if (A0_LDS && d == 0) { if (wave == 0) a0lds[ks * 64 + lane] = atab[(ks * 4) * 64 + lane]; }
-                else a[ks][d] = as_i32x4(atab[(ks * 4 + d) * 64 + lane]);
-            }
+                for (int d = 0; d < 4; ++d) {
+                    if (A0_LDS && d == 0) { if (wave == 0) a0lds[ks * 64 + lane] = atab[(ks * 4) * 64 + lane]; }
+                    else a[ks][0][d] = as_i32x4(atab[(ks * 4 + d) * 64 + lane]);
+                }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) a[ks][pp][d] = i32x4{0, 0, 0, 0};
+        }
         // dynamic order: the digits are waited for here, once -- left to their first use inside the loop,
         // the wait (s_waitcnt vmcnt(0) between two MFMAs) stays in every phase of that loop and then also
         // waits for the acknowledgement of the stores the wave has just issued (the counted loop of the
@@ -1593,12 +1725,12 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
 #pragma unroll
             for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
-                for (int d = (A0_LDS ? 1 : 0); d < 4; ++d) asm volatile("" ::"v"(a[ks][d]));
+                for (int d = (A0_LDS ? 1 : 0); d < 4; ++d) asm volatile("" ::"v"(a[ks][0][d]));
         }
         // 128 * (sum of the row's digits), combined over the digits exactly as the accumulators are
         // below: it undoes the -128 of the low bytes, and because the combination is the same sequence
         // of float32 operations on the negated integers, zero samples still give an exact zero
-        const f32x4 bias = S8 ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, btab[lane]);
+        f32x4 bias = (S8 || CPX) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, btab[lane]);
         if (DYN && !S8) asm volatile("" ::"v"(bias));          // (waited for here, like the digits above)
         // hi plane of component j&1, this lane's group within a column block, step 0
         const int bofs = (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq + CBW * wave * (16 * g.D * 8);
@@ -1633,16 +1765,36 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             }
             // the tile before the last
             if (FIN != 1 && t_fin >= 0 && !(SDR_I8_ABL & 4))
-                i8_finish<(FIN == 2 ? R / 2 : R), NCB, S8>(g, outv, (const float *)ybuf, p & 1, tid, t_fin, in, ftaps);
+            {
+                if constexpr (CPX) i8_finish_cpx<(FIN == 2 ? R / 2 : R), NCB, S8>(g, outv, (const float *)ybuf, p & 1, tid, t_fin, in, ftaps);
+                else i8_finish<(FIN == 2 ? R / 2 : R), NCB, S8>(g, outv, (const float *)ybuf, p & 1, tid, t_fin, in, ftaps);
+            }
             if (DYN && wave == 0 && lane == 0) q_drawn = i8_draw(qctr, 1u);
             clk.mark(2);
             const bool work = tile_of(p - 1) >= 0 && !(SDR_I8_ABL & 1);
+            if constexpr (CPX) {
+                // this tile's channel: its digits (and the low-byte bias that goes with them) become resident
+                if (work) {
+                    const int chm = i8_tile_channel(g, tile_of(p - 1));
+                    if (chm != ch_loaded) {
+                        ch_loaded = chm;
+                        const uint4 *ac = atab + (size_t)(g.chan_first + chm) * (NS * NP * 4 * 64) + lane;
+#pragma unroll
+                        for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+                            for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) a[ks][pp][d] = as_i32x4(ac[((ks * NP + pp) * 4 + d) * 64]);
+                        if (!S8) bias = __builtin_bit_cast(f32x4, btab[(size_t)(g.chan_first + chm) * 64 + lane]);
+                    }
+                }
+            }
             if (work) {
                 const unsigned char *bbase = smem + ((p - 1) & 1) * buf_bytes + bofs;
                 // units of (column block, step), samples requested PD units ahead (int8 samples: a unit
                 // is four MFMAs, 64 cycles, so the LDS round trip needs the longer lead)
                 constexpr int UNITS = CBW * NS;
-                constexpr int PD = S8 ? 4 : 2, NB = PD + 1;
+                constexpr int PD = CPX ? (S8 ? 2 : 1) : (S8 ? 4 : 2), NB = PD + 1;
                 i32x4 b[NB][3];                                // [buffer][hi, lo, lowest tap digit]
 #pragma unroll
                 for (int u = 0; u < PD && u < UNITS; ++u) {
@@ -1652,6 +1804,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     if (A0_LDS) b[u][2] = as_i32x4(a0lds[(u % NS) * 64 + lane]);
                 }
                 i32x4 acc[4];                                  // weights 2^8 .. 2^32
+                i32x4 acci[CPX ? 4 : 1];                       // complex taps: the imaginary part's sums
 #pragma unroll
                 for (int u = 0; u < UNITS; ++u) {
                     const int cb = u / NS, ks = u % NS;
@@ -1665,34 +1818,63 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     if (ks == 0) {
 #pragma unroll
                         for (int w = 0; w < 4; ++w) acc[w] = i32x4{0, 0, 0, 0};
+                        if constexpr (CPX) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) acci[w] = i32x4{0, 0, 0, 0};
+                        }
                     }
                     if (ks < NS - 3 || ks < g.ngran) {         // wave-uniform
                         const i32x4 xh = b[u % NB][0];
-                        const i32x4 a0 = A0_LDS ? b[u % NB][2] : a[ks][0];
+                        const i32x4 a0 = A0_LDS ? b[u % NB][2] : a[ks][0][0];
                         if constexpr (S8) {
                             // one byte per sample: digit w x sample, accumulator w
                             acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, xh, acc[0], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][1], xh, acc[1], 0, 0, 0);
-                            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xh, acc[2], 0, 0, 0);
-                            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xh, acc[3], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][1], xh, acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][2], xh, acc[2], 0, 0, 0);
+                            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][3], xh, acc[3], 0, 0, 0);
+                            if constexpr (CPX) {
+#pragma unroll
+                                for (int w = 0; w < 4; ++w) acci[w] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][w], xh, acci[w], 0, 0, 0);
+                            }
                         } else {
                         const i32x4 xl = b[u % NB][1];
                         // weight w = digit + (hi ? 1 : 0), accumulator w - 1; the weight-0 product (lowest
                         // digit x low byte, < 2^-30 of full scale) is left out: seven products, not eight.
                         // No accumulator twice in a row.
-                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][1], xl, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xl, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xl, acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][3], xh, acc[3], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][1], xl, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][2], xl, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][3], xl, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][3], xh, acc[3], 0, 0, 0);
                         acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, xh, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][1], xh, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][2], xh, acc[2], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][1], xh, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][2], xh, acc[2], 0, 0, 0);
+                        if constexpr (CPX) {
+                            acci[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][1], xl, acci[0], 0, 0, 0);
+                            acci[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][2], xl, acci[1], 0, 0, 0);
+                            acci[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][3], xl, acci[2], 0, 0, 0);
+                            acci[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][3], xh, acci[3], 0, 0, 0);
+                            acci[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][0], xh, acci[0], 0, 0, 0);
+                            acci[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][1], xh, acci[1], 0, 0, 0);
+                            acci[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][2], xh, acci[2], 0, 0, 0);
+                        }
                         }
                     }
                     if (ks == NS - 1) {
                         // y = yscale * sum of 2^(8w) * acc[w] (the common 2^8 sits in yscale): the only
                         // floating-point step, a fixed sequence on exact integers.  Balanced digits: the
                         // top term carries the value, the rest is a correction -- nothing cancels.
+                        if constexpr (CPX) {
+                            // real output (the I column, even lane) = Gr*Xi - Gi*Xq, imaginary (the Q column,
+                            // odd lane) = Gr*Xq + Gi*Xi: the other column's "imaginary" sums come from the
+                            // adjacent lane (quad_perm 1,0,3,2), exact in int32
+#pragma unroll
+                            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int other = __builtin_amdgcn_mov_dpp(acci[w][r], 0xB1, 0xF, 0xF, true);
+                                    acc[w][r] = (j & 1) ? acc[w][r] + other : acc[w][r] - other;
+                                }
+                        }
                         f32x4 rv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -1782,7 +1964,10 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             request(t_req, w, tl);
             clk.mark(1);
             if (FIN != 0 && t_fin >= 0 && !(SDR_I8_ABL & 4))
-                i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB, S8>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin, in, ftaps);
+            {
+                if constexpr (CPX) i8_finish_cpx<(FIN == 2 ? NCB / 4 : NCB / 2), NCB, S8>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin, in, ftaps);
+                else i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB, S8>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin, in, ftaps);
+            }
             if constexpr (DYN) tq_snap = tq_in;
             clk.arrive();
             lds_only_barrier();
@@ -1846,6 +2031,8 @@ struct sdr_fir_plan {
     float4 *d_atab = nullptr;   // its A-operand table
     bool ksplit = false;    // fir_ksplit_kernel (real input, short streams: taps split over the four waves of a workgroup)
     bool mfma_i8 = false;   // fir_mfma_i8_kernel (byte-split Toeplitz GEMM on the int8 matrix pipe, persistent)
+    bool cpx = false;       // ... with complex taps per channel (the channelizer's mixers folded into the taps)
+    float2 *d_chan_e = nullptr;   // its per-channel output-step phasors exp(j*2*pi*fr*D)
     uint4 *d_atab8 = nullptr;   // its A-operand table (tap digits)
     uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave
     // Tile counters of its dynamic hand-out (i8_draw): a ring of kQueueBlocks blocks of kI8QueueWords, one
@@ -2008,10 +2195,10 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
                 }
             }
         }
-#define SDR_I8K(NS, CB, PRE, S8, DYN)                                                            \
+#define SDR_I8K(NS, CB, PRE, S8, DYN, ...)                                                       \
     do {                                                                                         \
-        SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN>));                                  \
-        fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
+        SDR_OPT_IN((fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN, ##__VA_ARGS__>));                   \
+        fir_mfma_i8_kernel<NS, CB, PRE, S8, DYN, ##__VA_ARGS__><<<nb, 512, p->lds_bytes, st>>>((const uint32_t *)in, out, p->d_atab8, p->d_btab8, g, \
                                                                   p->plane_bytes, p->yscale,                 \
                                                                   p->d_ftaps, qctr, q_done, q_gen); \
     } while (0)
@@ -2027,6 +2214,13 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         // lanes' registers): their windows have more than four steps and their tiles more than four
         // octets per lane, so those instantiations do not exist (a wider one would do the same work)
         const int ns = (p->ngran + 3) / 4;
+        if (p->cpx) {
+            // complex taps per channel: four steps, tiles of 1024 outputs, contiguous runs of tiles
+#define SDR_I8C(PRE, S8) SDR_I8K(4, 8, PRE, S8, false, true)
+            if (p->input == SDR_IN_I8_IQ) { if (pre <= 4) SDR_I8C(4, true); else if (pre <= 6) SDR_I8C(6, true); else SDR_I8C(8, true); }
+            else { if (pre <= 4) SDR_I8C(4, false); else if (pre <= 6) SDR_I8C(6, false); else SDR_I8C(8, false); }
+#undef SDR_I8C
+        } else
         if (p->R == 4) { if (ns <= 1) SDR_I8(4, 8); else if (ns == 2) SDR_I8(8, 8); else SDR_I8(12, 8); }
         else if (ns <= 2) SDR_I8(8, 4);
         else SDR_I8(12, 4);
@@ -2124,7 +2318,7 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
             sdr::set_error("channels [%lld, %lld) but the plan has %d channel mixers", chan_first, chan_first + (long long)n_ch, p->n_chan_mix);
             return SDR_EINVAL;
         }
-        g.chan_fr = p->d_chan_fr; g.chan_tab = p->d_chan_tab; g.chan_first = (int)chan_first; g.chan_tab_stride = p->chan_tab_stride;
+        g.chan_fr = p->d_chan_fr; g.chan_tab = p->cpx ? p->d_chan_e : p->d_chan_tab; g.chan_first = (int)chan_first; g.chan_tab_stride = p->chan_tab_stride;
     }
     g.scale = (float)p->scale;
     // with the discriminator a tile's last lane only supplies its neighbour's successor y
@@ -2190,7 +2384,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     (void)hipGetDevice(&p->device);
     const bool raw_possible = ((d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI) && d->mix_fr == 0.0 && !chan_mix);
     // the int8 matrix kernel also takes int8 sample pairs (one byte plane per component)
-    const bool i8_possible = raw_possible || (d->input == SDR_IN_I8_IQ && d->mix_fr == 0.0 && !chan_mix);
+    const bool int_input = d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI || d->input == SDR_IN_I8_IQ;
+    // (channelizer plans: the per-channel mixer folded into complex taps, windows of up to 256 samples)
+    const bool i8_possible = int_input && d->mix_fr == 0.0;
     if ((d->pipeline == 1 || d->pipeline == 3 || d->pipeline == 4) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3 and 4 need int16 input without mixer"); return SDR_EINVAL; }
     if (d->pipeline == 5 && !i8_possible) { delete p; sdr::set_error("pipeline 5 needs int16 or int8 input without mixer"); return SDR_EINVAL; }
     const bool ksplit_possible = d->input == SDR_IN_F32_REAL && d->mode != SDR_MODE_FM;
@@ -2262,8 +2458,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         const double tiles_per_cu = (big ? 1024.0 : 2048.0) / (double)d->decim;
         const double t_hbm = ((s8 ? 2.0 : 4.0) + 4.0 / d->decim) * 268435456.0 / 5.4e12 * 1e3;
         const double t_i8 = std::fmax(t_hbm, tiles_per_cu * tile_us * 1e-3);
-        auto_i8 = t_i8 < t_valu;
-        if (d->size_hint > 0) {
+        auto_i8 = t_i8 < t_valu || chan_mix;     // channelizer: 2.7x the float-tile kernel with per-channel tables
+        if (d->size_hint > 0 && !chan_mix) {
             // a launch of the persistent matrix kernel costs ~13 us before its first output (tap digits
             // into registers, three pipeline stages), one of the tile kernels ~4 us: short launches
             // (below 2^26 samples at the headline shape, 2^22 at 511 / 10) stay on the vector unit
@@ -2287,6 +2483,11 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         gm.Tback = roundup(p->T - 1, 4);
         const int W = gm.Tback + 15 * p->D + 1;
         const int nks = (W + 63) / 64;
+        if (chan_mix && nks > 4) {
+            // complex taps double the digit registers: four steps (256 samples) at most
+            if (!auto_i8) { sdr::set_error("pipeline 5 with per-channel mixers: window of %d samples exceeds 256 (decim=%d taps=%d)", W, p->D, p->T); delete p; return SDR_EINVAL; }
+            fits = false;
+        }
         if (nks > kI8MaxSteps) {
             if (!auto_i8) { sdr::set_error("pipeline 5: window of %d samples exceeds %d (decim=%d taps=%d)", W, 64 * kI8MaxSteps, p->D, p->T); delete p; return SDR_EINVAL; }
             fits = false;
@@ -2338,9 +2539,14 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             if (!auto_i8) { sdr::set_error("pipeline 5: tile does not fit in LDS (decim=%d taps=%d)", p->D, p->T); delete p; return SDR_EINVAL; }
             fits = false;
         }
+        if (fits && chan_mix && ncb != 8) {
+            if (!auto_i8) { sdr::set_error("pipeline 5 with per-channel mixers needs tiles of 1024 outputs (decim=%d taps=%d)", p->D, p->T); delete p; return SDR_EINVAL; }
+            fits = false;
+        }
         if (fits) {
             best = gm; bestR = ncb / 2; bestNT = 256; best_raw = true;   // 256 finishing lanes, two or four outputs each
             p->mfma_i8 = true;
+            p->cpx = chan_mix;
         }
     }
     // Short real-input streams (the plan's size hint): when the streaming kernel would put fewer than two
@@ -2489,7 +2695,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         phasor_tables(p->mix_fr, p->n_ph_hi, gt);
     }
     std::vector<float> chan_tab;
-    if (chan_mix) {
+    if (chan_mix) p->n_chan_mix = d->n_mix_channels;
+    if (chan_mix && !p->cpx) {
         // the channelizer: one pair of tables per channel (frequency_shift / create_freq_rotation per
         // channel, bladerf_apt_demod.cpp:476-495, sdr_functions.h:63-74), ~1 KB each
         p->n_ph_hi = ph_hi_entries(p->s_gran);
@@ -2514,6 +2721,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             }
     }
     std::vector<uint4> at8, bt8;
+    std::vector<float> chan_e;
     if (p->mfma_i8) {
         // taps as 31-bit fixed point q = round(h * 2^F), F from the largest tap, in four balanced
         // base-256 digits; atab8[wave][s][digit][lane] = sixteen digits of H[i][64*ks + 16*kq + c],
@@ -2537,16 +2745,15 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         for (int i = 0; i < p->T; ++i) p->zfix |= (std::llabs(q[i]) < 128 && d->taps[i] != 0.0);
         // Q11 samples, the kernel's sums start at weight 2^8 (int16) | Q7 samples, sums from weight 2^0 (int8)
         p->yscale = (float)std::ldexp(1.0, p->input == SDR_IN_I8_IQ ? -(F + 7) : -(F + 11) + 8);
-        std::vector<int> rowsum((size_t)4 * 16, 0);            // [digit][row]
-        at8.assign((size_t)kI8MaxSteps * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
-        {
-            for (int ks = 0; ks < kI8MaxSteps; ++ks)
+        // sixteen-digit groups of one tap set: dst[(ks * ks_stride + digit) * 64 + lane], row sums added to rowsum[digit][row]
+        auto digits_of = [&](const std::vector<long long> &qq, int n_steps, size_t ks_stride, uint4 *dst, int *rowsum) {
+            for (int ks = 0; ks < n_steps; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
                     unsigned char dg[4][16];
                     for (int c = 0; c < 16; ++c) {
                         const long long k = 64LL * ks + 16 * (lane >> 4) + c;
                         const long long t = (long long)p->D * (lane & 15) + p->Tback - k;
-                        long long r = (t >= 0 && t < p->T) ? q[t] : 0;
+                        long long r = (t >= 0 && t < p->T) ? qq[t] : 0;
                         for (int di = 0; di < 4; ++di) {
                             const long long dgt = ((r + 128) & 255) - 128;       // balanced digit in [-128, 127]
                             dg[di][c] = (unsigned char)(dgt & 255);
@@ -2558,25 +2765,59 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                         uint32_t v[4];
                         for (int u = 0; u < 4; ++u)
                             v[u] = dg[di][4 * u] | ((uint32_t)dg[di][4 * u + 1] << 8) | ((uint32_t)dg[di][4 * u + 2] << 16) | ((uint32_t)dg[di][4 * u + 3] << 24);
-                        at8[((size_t)ks * 4 + di) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
+                        dst[((size_t)ks * ks_stride + di) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
                     }
                 }
-        }
-        // bt8[lane]: lane (j, kq) holds rows 4*kq + 0..3 of every column; digit d meets the low bytes in
-        // accumulator d-1 (weight 0, digit 0, is not computed): 128 * rowsum, combined like the
-        // kernel's accumulators
-        bt8.assign((size_t)64, make_uint4(0u, 0u, 0u, 0u));
-        for (int lane = 0; lane < 64; ++lane) {
+        };
+        // bias of lane (j, kq): rows 4*kq + 0..3; digit d meets the low bytes in accumulator d-1 (weight 0,
+        // digit 0, is not computed): 128 * rowsum, combined like the kernel's accumulators
+        auto bias_of = [](const int *rs, int lane) {
             float bf[4];
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * (lane >> 4) + r;
-                const float lo = std::fmaf((float)(128 * rowsum[32 + row]), 256.0f, (float)(128 * rowsum[16 + row]));
-                const float hi = std::fmaf(0.0f, 256.0f, (float)(128 * rowsum[48 + row]));
+                const float lo = std::fmaf((float)(128 * rs[32 + row]), 256.0f, (float)(128 * rs[16 + row]));
+                const float hi = std::fmaf(0.0f, 256.0f, (float)(128 * rs[48 + row]));
                 bf[r] = std::fmaf(hi, 65536.0f, lo);
             }
             uint4 u;
             std::memcpy(&u, bf, 16);
-            bt8[lane] = u;
+            return u;
+        };
+        if (!p->cpx) {
+            std::vector<int> rowsum((size_t)4 * 16, 0);            // [digit][row]
+            at8.assign((size_t)kI8MaxSteps * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
+            digits_of(q, kI8MaxSteps, 4, at8.data(), rowsum.data());
+            bt8.assign((size_t)64, make_uint4(0u, 0u, 0u, 0u));
+            for (int lane = 0; lane < 64; ++lane) bt8[lane] = bias_of(rowsum.data(), lane);
+        } else {
+            // the channelizer: per channel the digits of Re g and Im g, g[i] = h[i] * exp(-j*2*pi*fr*i) (phase
+            // reduced in double), laid out [channel][step][part][digit][lane]; the bias of an even lane (real
+            // output = Gr*Xi - Gi*Xq) comes from the row sums' difference, of an odd lane from their sum
+            constexpr int NSC = 4;
+            at8.assign((size_t)p->n_chan_mix * NSC * 2 * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
+            bt8.assign((size_t)p->n_chan_mix * 64, make_uint4(0u, 0u, 0u, 0u));
+            chan_e.resize((size_t)p->n_chan_mix * 2);
+            std::vector<long long> qr(p->T), qi(p->T);
+            p->zfix = true;      // the discriminator's shortcut (a constant turn of the product) needs every exact zero looked at
+            for (int c = 0; c < p->n_chan_mix; ++c) {
+                const double fr = d->mix_fr_channels[c];
+                for (int i = 0; i < p->T; ++i) {
+                    const double ph = fr * (double)i, f = ph - std::rint(ph);
+                    qr[i] = std::llround(std::ldexp(d->taps[i] * std::cos(2.0 * M_PI * f), F));
+                    qi[i] = std::llround(std::ldexp(-d->taps[i] * std::sin(2.0 * M_PI * f), F));
+                }
+                std::vector<int> rs_r(64, 0), rs_i(64, 0), rs(64, 0);
+                uint4 *dst = at8.data() + (size_t)c * NSC * 2 * 4 * 64;
+                digits_of(qr, NSC, 8, dst, rs_r.data());
+                digits_of(qi, NSC, 8, dst + 4 * 64, rs_i.data());
+                for (int lane = 0; lane < 64; ++lane) {
+                    for (int k = 0; k < 64; ++k) rs[k] = (lane & 1) ? rs_r[k] + rs_i[k] : rs_r[k] - rs_i[k];
+                    bt8[(size_t)c * 64 + lane] = bias_of(rs.data(), lane);
+                }
+                const double phd = fr * (double)p->D, fd = phd - std::rint(phd);
+                chan_e[2 * (size_t)c] = (float)std::cos(2.0 * M_PI * fd);
+                chan_e[2 * (size_t)c + 1] = (float)std::sin(2.0 * M_PI * fd);
+            }
         }
     }
     hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
@@ -2589,8 +2830,10 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (e == hipSuccess && p->mfma) e = hipMalloc((void **)&p->d_atab, at.size() * sizeof(float4));
     if (e == hipSuccess && p->mfma) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_gtab, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && chan_mix) e = hipMalloc((void **)&p->d_chan_tab, chan_tab.size() * sizeof(float));
-    if (e == hipSuccess && chan_mix) e = hipMemcpy(p->d_chan_tab, chan_tab.data(), chan_tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && chan_mix && !p->cpx) e = hipMalloc((void **)&p->d_chan_tab, chan_tab.size() * sizeof(float));
+    if (e == hipSuccess && chan_mix && !p->cpx) e = hipMemcpy(p->d_chan_tab, chan_tab.data(), chan_tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && p->cpx) e = hipMalloc((void **)&p->d_chan_e, chan_e.size() * sizeof(float));
+    if (e == hipSuccess && p->cpx) e = hipMemcpy(p->d_chan_e, chan_e.data(), chan_e.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && chan_mix) e = hipMalloc((void **)&p->d_chan_fr, (size_t)p->n_chan_mix * sizeof(double));
     if (e == hipSuccess && chan_mix) e = hipMemcpy(p->d_chan_fr, d->mix_fr_channels, (size_t)p->n_chan_mix * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -2599,7 +2842,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     }
     if (p->mfma_i8 && d->pipeline == 0) {
         sdr_fir_desc d2 = *d;
-        d2.pipeline = d->input == SDR_IN_I8_IQ ? 2 : 1;        // float tiles | raw tile
+        d2.pipeline = (d->input == SDR_IN_I8_IQ || chan_mix) ? 2 : 1;        // float tiles | raw tile
         if (sdr_fir_plan_create(&d2, &p->tiny) != SDR_OK) p->tiny = nullptr;
     }
     *out = p;
@@ -2619,6 +2862,7 @@ extern "C" int sdr_fir_plan_destroy(sdr_fir_plan *p)
     if (p->d_ftaps) (void)hipFree(p->d_ftaps);
     if (p->d_chan_tab) (void)hipFree(p->d_chan_tab);
     if (p->d_chan_fr) (void)hipFree(p->d_chan_fr);
+    if (p->d_chan_e) (void)hipFree(p->d_chan_e);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     delete p;

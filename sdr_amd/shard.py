@@ -14,9 +14,17 @@ from dataclasses import dataclass
 MODE_IQ, MODE_FM, MODE_ENV, MODE_REAL = 0, 1, 2, 3
 
 
-def out_count(n_samples, decim, mode):
-    """floor(N/D) outputs (bladerf_apt_demod.cpp:282), one fewer for the discriminator (:409)."""
-    ny = n_samples // decim
+COUNT_FLOOR, COUNT_AF_SEQ = 0, 1
+
+
+def out_count(n_samples, decim, mode, count_rule=COUNT_FLOOR):
+    """floor(N/D) outputs (bladerf_apt_demod.cpp:282) -- or, with COUNT_AF_SEQ, every index 0, D, ... <= N-1
+    as x3(af::seq(0, N, D)) picks them (bladerf_fm_demod.cpp:212,294; sdr_hip.h sdr_count_rule) -- one
+    fewer for the discriminator (:409)."""
+    if count_rule == COUNT_AF_SEQ:
+        ny = (n_samples - 1) // decim + 1 if n_samples > 0 else 0
+    else:
+        ny = n_samples // decim
     if mode == MODE_FM:
         return max(ny - 1, 0)
     return ny
@@ -39,9 +47,9 @@ class TimeShard:
         return self.hi - self.lo
 
 
-def plan_time_shards(n_total, decim, n_taps, mode, world):
+def plan_time_shards(n_total, decim, n_taps, mode, world, count_rule=COUNT_FLOOR):
     """Contiguous output ranges with the input window (own samples + halo) each rank must hold."""
-    cnt = out_count(n_total, decim, mode)
+    cnt = out_count(n_total, decim, mode, count_rule)
     shards = []
     for r in range(world):
         ob, oe = cnt * r // world, cnt * (r + 1) // world

@@ -1088,8 +1088,11 @@ def test_channelizer_per_channel_mixers(sdr, oracle, kind, T, D):
     chan_first (a rank's shard) equals the same channels of the whole launch bit for bit."""
     rng = np.random.default_rng(T * 13 + D)
     n_ch, n = 11, 60_000 + 7 * D + 3
-    frs = np.concatenate(([0.0, 0.25, -0.5], rng.uniform(-0.5, 0.5, n_ch - 3)))
-    h = oracle.create_fir_filter(T, 0.4 / D, "hann")
+    # channel centres 0.09 apart (well outside each other's pass band, so every channel holds ONE constant-
+    # envelope FM carrier and its angles are well conditioned), off the grid by a random bit, 0 and -0.45 exact
+    frs = (np.arange(n_ch) - 5) * 0.09 + rng.uniform(-0.003, 0.003, n_ch)
+    frs[5], frs[0] = 0.0, -0.45
+    h = oracle.create_fir_filter(T, min(0.4 / D, 0.05), "hann")
     # wideband test signal: an FM carrier at every channel's frequency (so that each channel, once mixed to
     # zero, holds a constant-envelope FM signal) plus noise
     t = np.arange(n)
@@ -1116,6 +1119,10 @@ def test_channelizer_per_channel_mixers(sdr, oracle, kind, T, D):
     d_in = sdr.DevBuf.from_numpy(raw)
     for mode, dt, eb in ((sdr.MODE_FM, np.float32, 4), (sdr.MODE_ENV, np.float32, 4), (sdr.MODE_IQ, np.complex64, 8)):
         plan = sdr.FirPlan(h, D, mode=mode, input=inp, mix_fr_channels=frs)
+        # integer input with a window of up to 256 samples: the int8 matrix kernel with the mixers folded
+        # into complex taps; else the float-tile kernel with per-channel phasor tables
+        want_kernel = "mfma_i8" if kind != "cf32" and (T - 1 + 3) // 4 * 4 + 15 * D + 1 <= 256 else "stream"
+        assert plan.info()["kernel"] == want_kernel, (plan.info(), want_kernel)
         cnt = plan.out_count(n)
         stride = cnt + 3
         SENT = 0x7FC0DEAD
@@ -1161,6 +1168,56 @@ def test_channelizer_per_channel_mixers(sdr, oracle, kind, T, D):
         sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp).execute_channels_dev(d_in, n, 0, 0, 1, d_out, stride)
     with pytest.raises(sdr.SdrError):
         sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp, mix_fr=0.1, mix_fr_channels=frs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,T,D", [("i16", 64, 10), ("i16", 101, 5), ("i8", 64, 10), ("i16", 64, 1)])
+def test_channelizer_matrix_kernel_zero_runs(sdr, oracle, kind, T, D):
+    """The complex-tap matrix kernel computes z[m] = y[m] e^{-jw mD} and turns the discriminator's product by
+    a constant instead of turning every y (i8_finish_cpx).  Where the reference's y is an exact zero -- zero
+    pre-history, zero runs in mid-stream -- its output is 0 or +-pi by the signs of the OTHER y's components,
+    and those are the mixed signal's signs: every lane that holds an exact zero goes back to the reference's
+    own arithmetic (i8_zero_fix).  Streams with zero runs, lone samples and sub-resolution taps, per channel
+    against the oracle with the exact-zero rule of check_fm; all-zero streams stay exactly zero."""
+    rng = np.random.default_rng(T * 5 + D)
+    h = oracle.create_fir_filter(T, min(0.8 / D, 0.45), "hann")
+    h[1], h[-1] = -3e-14, 2e-15                    # sub-resolution taps next to the Hann window's exact zeros
+    n = 24 * 1024 + 321 + 3 * D
+    if kind == "i8":
+        raw = rng.integers(-128, 128, 2 * n).astype(np.int8)
+        inp, unpack = sdr.IN_I8_IQ, oracle.unpack_scale_i8
+    else:
+        raw = rng.integers(-2000, 2001, 2 * n).astype(np.int16)
+        inp, unpack = sdr.IN_I16_IQ, oracle.unpack_scale_i16
+    for i, (a, b) in enumerate([(2_000, 2_000 + 3 * T + 5), (1024 * D - T - 3, 1024 * D + 2 * T + 1), (7_001, 7_001 + T - 7)]):
+        if b >= n - 2 * T:
+            continue
+        b = (b + D - 1) // D * D - (i & 1)
+        raw[2 * a: 2 * b] = 0
+    z0 = 12_000
+    z1 = min(n - 3 * T, z0 + 10 * T + 30 * D)
+    raw[2 * z0: 2 * z1] = 0
+    for k, s_ in enumerate(range(z0 + T + 3, z1 - T, 2 * T + 3 * D + 1)):
+        raw[2 * s_] = (-1) ** k * 77
+        raw[2 * s_ + 1] = 55 if k % 3 else -91
+    frs = np.array([0.0371, -0.2, 0.25, 0.0, -0.4999])
+    plan = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=inp, mix_fr_channels=frs)
+    assert plan.info()["kernel"] == "mfma_i8"
+    cnt = plan.out_count(n)
+    d_in = sdr.DevBuf.from_numpy(raw)
+    d_out = sdr.DevBuf(cnt * frs.size * 4)
+    plan.execute_channels_dev(d_in, n, 0, 0, frs.size, d_out, cnt)
+    sdr.sync()
+    out = d_out.to_numpy(np.float32, cnt * frs.size).reshape(frs.size, cnt)
+    xs = unpack(raw)
+    for c, fr in enumerate(frs):
+        y = oracle.fir_decimate(oracle.frequency_shift(xs, fr), D, h)
+        assert (np.abs(y) == 0).sum() >= 2 * T // D
+        check_fm(out[c], oracle.polar_discriminator(y, 1 / TWO_PI), y, 1 / TWO_PI, f"channelizer zero runs {kind} {T}/{D} fr {fr}", good_rel=None)
+    d_z = sdr.DevBuf.from_numpy(np.zeros_like(raw))
+    plan.execute_channels_dev(d_z, n, 0, 0, frs.size, d_out, cnt)
+    sdr.sync()
+    assert not d_out.to_numpy(np.float32, cnt * frs.size).any()
 
 
 @pytest.mark.gpu

@@ -32,6 +32,13 @@ def test_time_shard_plan_covers_outputs_and_halos():
             assert 0 <= s.lo <= max(0, s.out_begin * D - (T - 1))
             need_hi = (s.out_end - 1 + (1 if mode == shard.MODE_FM else 0)) * D + 1
             assert s.hi >= min(n, need_hi) and s.hi <= n
+    # the ArrayFire loops' count rule (one more y unless D divides N): the last shard reaches it
+    for (n, D, T, mode, world) in [(131072, 5, 101, shard.MODE_FM, 2), (100_001, 10, 64, shard.MODE_ENV, 3), (7, 10, 64, shard.MODE_IQ, 2)]:
+        sh = shard.plan_time_shards(n, D, T, mode, world, shard.COUNT_AF_SEQ)
+        ny = (n - 1) // D + 1
+        assert sh[-1].out_end == shard.out_count(n, D, mode, shard.COUNT_AF_SEQ) == (ny - 1 if mode == shard.MODE_FM else ny)
+        last = [s for s in sh if s.n_out][-1]
+        assert last.hi == min(n, (ny - 1) * D + 1)
     assert shard.plan_channel_shards(1024, 8) == [(128 * r, 128) for r in range(8)]
     assert shard.plan_channel_shards(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
     fs = shard.plan_frame_shards(1 << 20, 4096, 2048, 4)
@@ -104,12 +111,20 @@ def _chan_worker(rank, world, port, q):
     for c in range(c0, c0 + k):
         iq = O.synth_fm_i16(n, fs=1.0e6, ftone=300.0 + 100.0 * c, dev=5000.0)
         outs.append(O.chain_i16(iq, D, h, O.MODE_FM))
+    # the channelizer proper: every rank holds the same wideband buffer and runs ITS channels' mixers
+    # (sdr_fir_execute_channels_dev with chan_first = c0 on a GPU; here the oracle per channel)
+    wide = O.unpack_scale_i16(O.synth_fm_i16(n, fs=1.0e6, ftone=700.0, dev=20000.0))
+    frs = [0.05 * c - 0.12 for c in range(n_ch)]
+    for c in range(c0, c0 + k):
+        y = O.fir_decimate(O.frequency_shift(wide, frs[c]), D, h)
+        outs[c - c0] = outs[c - c0] + O.polar_discriminator(y, 1 / (2 * np.pi))
     local = np.concatenate(outs) if outs else np.zeros(0)
     per = shard.out_count(n, D, shard.MODE_FM)
     counts = [kk * per for (_, kk) in shard.plan_channel_shards(n_ch, world)]
     got = shard.gather_outputs(torch.from_numpy(local.copy()), counts, dist, dst=0)
     if rank == 0:
         want = np.concatenate([O.chain_i16(O.synth_fm_i16(n, fs=1.0e6, ftone=300.0 + 100.0 * c, dev=5000.0), D, h, O.MODE_FM)
+                               + O.polar_discriminator(O.fir_decimate(O.frequency_shift(wide, frs[c]), D, h), 1 / (2 * np.pi))
                                for c in range(n_ch)])
         q.put(bool(np.array_equal(got.numpy(), want)))
     dist.barrier()

@@ -139,6 +139,10 @@ int sdr_dev_free(void *ptr);
 int sdr_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int sdr_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 int sdr_dev_sync(void);
+/* Number of device / pinned-host allocations the library has made in this process, its own (plan tables,
+ * staging, scratch) and sdr_dev_alloc's.  A diagnostic with no reference counterpart: a steady-state
+ * caller -- the same filter block after block through the C++ shims or the hand-off -- sees it stand still. */
+unsigned long long sdr_alloc_count(void);
 
 /* ---- a11: filter design (host code, no kernel) ---------------------------------------------
  * Replaces DSP::create_fir_filter<T>(n_taps, fc, &DSP::xxx_window) and DSP::xxx_window(N) of the

@@ -80,27 +80,113 @@ private:
     sdr_fir_plan* p_ = nullptr;
 };
 
+// ---- per-thread plan cache and device scratch ---------------------------------------------------
+// The reference's functions carry no state: every call of polyphase_decimate / af::fir hands over the taps
+// again (bladerf_apt_demod.cpp:740,747; bladerf_fm_demod.cpp:291).  Building a plan per call -- tap upload,
+// geometry choice, device allocations -- costs more than filtering one 131072-sample block, so the shims
+// keep the plans they have built: a small per-thread LRU keyed by everything a plan depends on (the taps'
+// values, decimation, mode, input kind, scale, mixer, count rule, the block's size class).  A second call
+// with the same filter allocates nothing: the plan, its tap tables and its grow-only staging buffers
+// (sdr_fir_execute_host) are reused.  Per thread, because a plan's host staging serves one call at a time;
+// the reference calls its DSP from the one consumer thread.
+struct PlanKey {
+    std::vector<double> taps;
+    int decim, mode, input, count_rule, size_class;
+    double scale, mix_fr;
+    bool operator==(const PlanKey& o) const
+    {
+        return decim == o.decim && mode == o.mode && input == o.input && count_rule == o.count_rule &&
+               size_class == o.size_class && scale == o.scale && mix_fr == o.mix_fr && taps == o.taps;
+    }
+};
+
+class PlanCache {
+public:
+    static constexpr size_t kCapacity = 16;
+    ~PlanCache() { for (auto& e : entries_) sdr_fir_plan_destroy(e.plan); }
+    // size_hint: the samples a call hands over (0 = unknown); plans for block sizes within one power of two share an entry
+    sdr_fir_plan* get(const std::vector<double>& taps, int decim, int mode, int input, double scale, double mix_fr,
+                      int count_rule, long long size_hint)
+    {
+        int cls = 0;
+        for (long long v = size_hint; v > 1; v >>= 1) ++cls;
+        PlanKey key{taps, decim, mode, input, count_rule, size_hint > 0 ? cls : -1, scale, mix_fr};
+        for (size_t i = 0; i < entries_.size(); ++i)
+            if (entries_[i].key == key) {
+                if (i) std::rotate(entries_.begin(), entries_.begin() + i, entries_.begin() + i + 1);   // most recent first
+                return entries_.front().plan;
+            }
+        sdr_fir_desc d{};
+        d.input = input; d.mode = mode; d.decim = decim; d.n_taps = (int)taps.size();
+        d.taps = taps.data(); d.scale = scale; d.mix_fr = mix_fr; d.count_rule = count_rule;
+        d.size_hint = size_hint > 0 ? (1LL << cls) : 0;
+        sdr_fir_plan* plan = nullptr;
+        check(sdr_fir_plan_create(&d, &plan));
+        if (entries_.size() == kCapacity) { sdr_fir_plan_destroy(entries_.back().plan); entries_.pop_back(); }
+        entries_.insert(entries_.begin(), Entry{std::move(key), plan});
+        return plan;
+    }
+private:
+    struct Entry { PlanKey key; sdr_fir_plan* plan; };
+    std::vector<Entry> entries_;
+};
+inline PlanCache& plan_cache() { static thread_local PlanCache c; return c; }
+
+// host buffers in, host buffers out, through a cached plan
+template <class In, class Out>
+std::vector<Out> run_cached(const std::vector<double>& taps, int decim, int mode, int input, double scale, double mix_fr,
+                            int count_rule, const In* in, size_t n)
+{
+    sdr_fir_plan* plan = plan_cache().get(taps, decim, mode, input, scale, mix_fr, count_rule, (long long)n);
+    const size_t cnt = sdr_fir_out_count(plan, n);
+    std::vector<Out> out(std::max<size_t>(cnt, 1));
+    size_t n_out = 0;
+    check(sdr_fir_execute_host(plan, in, n, out.data(), cnt, &n_out));
+    out.resize(n_out);
+    return out;
+}
+
+// grow-only device scratch of the element-wise shims (frequency_shift, decimate_vec, the audio stage): a few
+// buffers per thread, allocated on first use and kept
+class Scratch {
+public:
+    ~Scratch() { for (void* q : p_) if (q) sdr_dev_free(q); }
+    void* get(int slot, size_t bytes)
+    {
+        if (bytes > cap_[slot]) {
+            if (p_[slot]) { sdr_dev_free(p_[slot]); p_[slot] = nullptr; cap_[slot] = 0; }
+            const size_t want = bytes + bytes / 4;
+            check(sdr_dev_alloc(&p_[slot], want));
+            cap_[slot] = want;
+        }
+        return p_[slot];
+    }
+private:
+    void* p_[3] = {nullptr, nullptr, nullptr};
+    size_t cap_[3] = {0, 0, 0};
+};
+inline Scratch& scratch() { static thread_local Scratch s; return s; }
+
 // ---- fused consumer-loop entry points (what the reference's while-loop body becomes) ---------
 // bladerf_apt_demod.cpp:728-742 in one call: int16 IQ -> scale -> FIR/D -> discriminator
 inline std::vector<float> fm_demod_i16(const std::vector<std::complex<int16_t>>& iq, int D,
                                        const std::vector<double>& h, double scale)
 {
-    FirPlan plan(h, D, SDR_MODE_FM, SDR_IN_I16_IQ, scale, 0.0, SDR_COUNT_FLOOR, (long long)iq.size());   // the block's size: kernel choice
-    return plan.run<std::complex<int16_t>, float>(iq.data(), iq.size());
+    // (the block's size picks the kernel: short blocks stay off the persistent matrix kernel)
+    return run_cached<std::complex<int16_t>, float>(h, D, SDR_MODE_FM, SDR_IN_I16_IQ, scale, 0.0, SDR_COUNT_FLOOR, iq.data(), iq.size());
 }
 // bladerf_am_demod.cpp:291-311 / bladerf_apt_demod.cpp:747-754: FIR/D -> |.|
 inline std::vector<float> envelope_i16(const std::vector<std::complex<int16_t>>& iq, int D,
                                        const std::vector<double>& h)
 {
-    FirPlan plan(h, D, SDR_MODE_ENV, SDR_IN_I16_IQ, 1.0, 0.0, SDR_COUNT_FLOOR, (long long)iq.size());
-    return plan.run<std::complex<int16_t>, float>(iq.data(), iq.size());
+    return run_cached<std::complex<int16_t>, float>(h, D, SDR_MODE_ENV, SDR_IN_I16_IQ, 1.0, 0.0, SDR_COUNT_FLOOR, iq.data(), iq.size());
 }
 // bladerf_apt_demod.cpp:744-754: frequency_shift -> polyphase_decimate -> abs on a real stream
 inline std::vector<float> shift_decimate_envelope(const std::vector<float>& x, double fr, int D,
                                                   const std::vector<double>& h)
 {
-    FirPlan plan(h, D, SDR_MODE_ENV, SDR_IN_F32_REAL, 1.0, fr, SDR_COUNT_FLOOR, (long long)x.size());   // short blocks: K-split kernel
-    return plan.run<float, float>(x.data(), x.size());
+    // (short blocks: the K-split kernel)
+    return run_cached<float, float>(h, D, SDR_MODE_ENV, SDR_IN_F32_REAL, 1.0, fr, SDR_COUNT_FLOOR, x.data(), x.size());
 }
 
 // bladerf_fm_demod.cpp:288-298 in one launch, on the float block the reference's source hands over:
@@ -109,24 +195,22 @@ inline std::vector<float> shift_decimate_envelope(const std::vector<float>& x, d
 inline std::vector<float> af_fir_pick_discriminate(const std::vector<std::complex<float>>& x2,
                                                    const std::vector<float>& lpf, int dec_rate, double phasor_scale)
 {
-    FirPlan plan(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_FM, SDR_IN_CF32, phasor_scale, 0.0,
-                 SDR_COUNT_AF_SEQ);
-    return plan.run<std::complex<float>, float>(x2.data(), x2.size());
+    return run_cached<std::complex<float>, float>(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_FM, SDR_IN_CF32,
+                                                  phasor_scale, 0.0, SDR_COUNT_AF_SEQ, x2.data(), x2.size());
 }
 // the same from the raw int16 block (the scale loop of bladerf_sdr.h:288-291 fused in as well)
 inline std::vector<float> af_fir_pick_discriminate_i16(const std::vector<std::complex<int16_t>>& iq,
                                                        const std::vector<float>& lpf, int dec_rate, double phasor_scale)
 {
-    FirPlan plan(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_FM, SDR_IN_I16_IQ, phasor_scale, 0.0,
-                 SDR_COUNT_AF_SEQ, (long long)iq.size());
-    return plan.run<std::complex<int16_t>, float>(iq.data(), iq.size());
+    return run_cached<std::complex<int16_t>, float>(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_FM, SDR_IN_I16_IQ,
+                                                    phasor_scale, 0.0, SDR_COUNT_AF_SEQ, iq.data(), iq.size());
 }
 // bladerf_am_demod.cpp:294-311: af::fir, x3(dec_seq), af::abs
 inline std::vector<float> af_fir_pick_abs(const std::vector<std::complex<float>>& x2, const std::vector<float>& lpf,
                                           int dec_rate)
 {
-    FirPlan plan(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_ENV, SDR_IN_CF32, 1.0, 0.0, SDR_COUNT_AF_SEQ);
-    return plan.run<std::complex<float>, float>(x2.data(), x2.size());
+    return run_cached<std::complex<float>, float>(std::vector<double>(lpf.begin(), lpf.end()), dec_rate, SDR_MODE_ENV, SDR_IN_CF32,
+                                                  1.0, 0.0, SDR_COUNT_AF_SEQ, x2.data(), x2.size());
 }
 
 // bladerf_fm_demod.cpp:301-313: de-emphasis FIR, audio low-pass FIR, pick every dec_audio-th sample,
@@ -141,17 +225,19 @@ inline std::vector<uint8_t> fm_audio_u8(const std::vector<float>& x5, const std:
     std::vector<double> hc(lpf_de.size() + lpf_a.size() - 1, 0.0);
     for (size_t i = 0; i < lpf_de.size(); ++i)
         for (size_t j = 0; j < lpf_a.size(); ++j) hc[i + j] += (double)lpf_de[i] * (double)lpf_a[j];
-    FirPlan plan(hc, dec_audio, SDR_MODE_REAL, SDR_IN_F32_REAL, 1.0, 0.0, count_rule, (long long)x5.size());
-    const size_t m = plan.out_count(x5.size());
+    sdr_fir_plan* plan = plan_cache().get(hc, dec_audio, SDR_MODE_REAL, SDR_IN_F32_REAL, 1.0, 0.0, count_rule, (long long)x5.size());
+    const size_t m = sdr_fir_out_count(plan, x5.size());
     std::vector<uint8_t> pcm(m);
     if (m == 0) return pcm;
-    DevMem d_in(x5.size() * sizeof(float)), d_a((m + 1) * sizeof(float)), d_pcm(m);   // d_a: audio + the max scratch
-    check(sdr_dev_upload(d_in.get(), x5.data(), x5.size() * sizeof(float)));
+    void* d_in = scratch().get(0, x5.size() * sizeof(float));
+    float* d_a = static_cast<float*>(scratch().get(1, (m + 1) * sizeof(float)));      // audio + the max scratch
+    uint8_t* d_pcm = static_cast<uint8_t*>(scratch().get(2, m));
+    check(sdr_dev_upload(d_in, x5.data(), x5.size() * sizeof(float)));
     size_t n_out = 0;
-    check(sdr_fir_execute_dev(plan.get(), d_in.get(), x5.size(), d_a.get(), m, &n_out, nullptr));
-    check(sdr_audio_u8_dev(d_a.as<float>(), m, d_a.as<float>() + m, d_pcm.as<uint8_t>(), nullptr));
+    check(sdr_fir_execute_dev(plan, d_in, x5.size(), d_a, m, &n_out, nullptr));
+    check(sdr_audio_u8_dev(d_a, m, d_a + m, d_pcm, nullptr));
     check(sdr_dev_sync());
-    check(sdr_dev_download(pcm.data(), d_pcm.get(), m));
+    check(sdr_dev_download(pcm.data(), d_pcm, m));
     return pcm;
 }
 
@@ -171,8 +257,8 @@ polyphase_decimate(const std::vector<std::complex<double>>& x, int32_t decimatio
         throw std::invalid_argument("Filter length must be a multiple of M.");
     std::vector<std::complex<float>> xf(x.size());
     for (size_t i = 0; i < x.size(); ++i) xf[i] = std::complex<float>((float)x[i].real(), (float)x[i].imag());
-    sdrhip::FirPlan plan(h, decimation_factor, SDR_MODE_IQ, SDR_IN_CF32);
-    const std::vector<std::complex<float>> yf = plan.run<std::complex<float>, std::complex<float>>(xf.data(), xf.size());
+    const std::vector<std::complex<float>> yf = sdrhip::run_cached<std::complex<float>, std::complex<float>>(
+        h, decimation_factor, SDR_MODE_IQ, SDR_IN_CF32, 1.0, 0.0, SDR_COUNT_FLOOR, xf.data(), xf.size());
     std::vector<std::complex<double>> y(yf.size());
     for (size_t i = 0; i < yf.size(); ++i) y[i] = std::complex<double>(yf[i].real(), yf[i].imag());
     return y;
@@ -185,8 +271,8 @@ std::vector<T> polar_discriminator(std::vector<std::complex<T>>& v1, double scal
 {
     std::vector<std::complex<float>> xf(v1.size());
     for (size_t i = 0; i < v1.size(); ++i) xf[i] = std::complex<float>((float)v1[i].real(), (float)v1[i].imag());
-    sdrhip::FirPlan plan(std::vector<double>{1.0}, 1, SDR_MODE_FM, SDR_IN_CF32, scale);
-    const std::vector<float> d = plan.run<std::complex<float>, float>(xf.data(), xf.size());
+    const std::vector<float> d = sdrhip::run_cached<std::complex<float>, float>(std::vector<double>{1.0}, 1, SDR_MODE_FM, SDR_IN_CF32, scale,
+                                                                                0.0, SDR_COUNT_FLOOR, xf.data(), xf.size());
     return std::vector<T>(d.begin(), d.end());
 }
 
@@ -197,11 +283,12 @@ inline std::vector<std::complex<double>> frequency_shift_impl(const float* in, i
     std::vector<std::complex<double>> res(n);
     if (n == 0) return res;
     const size_t bin = n * (is_complex ? 8 : 4);
-    DevMem d_in(bin), d_out(n * 8);
-    check(sdr_dev_upload(d_in.get(), in, bin));
-    check(sdr_frequency_shift_dev(d_in.as<float>(), is_complex, n, 0, fr, d_out.as<float>(), nullptr));
+    float* d_in = static_cast<float*>(scratch().get(0, bin));
+    float* d_out = static_cast<float*>(scratch().get(1, n * 8));
+    check(sdr_dev_upload(d_in, in, bin));
+    check(sdr_frequency_shift_dev(d_in, is_complex, n, 0, fr, d_out, nullptr));
     std::vector<std::complex<float>> out(n);
-    check(sdr_dev_download(out.data(), d_out.get(), n * 8));
+    check(sdr_dev_download(out.data(), d_out, n * 8));
     for (size_t i = 0; i < n; ++i) res[i] = std::complex<double>(out[i].real(), out[i].imag());
     return res;
 }
@@ -226,10 +313,10 @@ inline std::vector<std::complex<double>> create_freq_rotation(uint64_t N, double
 {
     std::vector<std::complex<double>> res(N);
     if (N == 0) return res;
-    sdrhip::DevMem d_out(N * 8);
-    sdrhip::check(sdr_frequency_shift_dev(nullptr, 1, N, 0, fr, d_out.as<float>(), nullptr));
+    float* d_out = static_cast<float*>(sdrhip::scratch().get(1, N * 8));
+    sdrhip::check(sdr_frequency_shift_dev(nullptr, 1, N, 0, fr, d_out, nullptr));
     std::vector<std::complex<float>> out(N);
-    sdrhip::check(sdr_dev_download(out.data(), d_out.get(), N * 8));
+    sdrhip::check(sdr_dev_download(out.data(), d_out, N * 8));
     for (size_t i = 0; i < N; ++i) res[i] = std::complex<double>(out[i].real(), out[i].imag());
     return res;
 }
@@ -252,11 +339,13 @@ std::vector<T> decimate_vec(std::vector<T>& v1, double rate)
     }
     std::vector<T> res(num);
     if (num == 0) return res;
-    sdrhip::DevMem d_in(v1.size() * sizeof(T)), d_idx(num * 8), d_out(num * sizeof(T));
-    sdrhip::check(sdr_dev_upload(d_in.get(), v1.data(), v1.size() * sizeof(T)));
-    sdrhip::check(sdr_dev_upload(d_idx.get(), idx.data(), num * 8));
-    sdrhip::check(sdr_gather_dev(d_in.get(), (int)(sizeof(T) / 4), v1.size(), d_idx.as<uint64_t>(), num, d_out.get(), nullptr));
-    sdrhip::check(sdr_dev_download(res.data(), d_out.get(), num * sizeof(T)));
+    void* d_in = sdrhip::scratch().get(0, v1.size() * sizeof(T));
+    uint64_t* d_idx = static_cast<uint64_t*>(sdrhip::scratch().get(1, num * 8));
+    void* d_out = sdrhip::scratch().get(2, num * sizeof(T));
+    sdrhip::check(sdr_dev_upload(d_in, v1.data(), v1.size() * sizeof(T)));
+    sdrhip::check(sdr_dev_upload(d_idx, idx.data(), num * 8));
+    sdrhip::check(sdr_gather_dev(d_in, (int)(sizeof(T) / 4), v1.size(), d_idx, num, d_out, nullptr));
+    sdrhip::check(sdr_dev_download(res.data(), d_out, num * sizeof(T)));
     return res;
 }
 
@@ -274,8 +363,8 @@ std::vector<T> filter_vec(std::vector<T>& v1, std::vector<U>& h)
     std::vector<float> vf(N + Th, 0.0f);
     for (uint64_t i = 0; i < N; ++i) vf[i] = (float)v1[i];
     std::vector<double> hd(h.begin(), h.end());
-    sdrhip::FirPlan plan(hd, 1, SDR_MODE_IQ, SDR_IN_F32_REAL);
-    const std::vector<std::complex<float>> y = plan.run<float, std::complex<float>>(vf.data(), vf.size());
+    const std::vector<std::complex<float>> y = sdrhip::run_cached<float, std::complex<float>>(hd, 1, SDR_MODE_IQ, SDR_IN_F32_REAL, 1.0, 0.0,
+                                                                                              SDR_COUNT_FLOOR, vf.data(), vf.size());
     const uint64_t shift = Th - 1 - h2;
     for (uint64_t idx = 0; idx + h2 < N; ++idx) res[idx] = (T)y[idx + shift].real();
     for (uint64_t idx = N - h2; idx < N; ++idx) {          // the reference's tail rows
@@ -301,15 +390,25 @@ inline std::vector<double> blackman_harris_window(int64_t N) { std::vector<doubl
 template <typename T>
 std::vector<T> create_fir_filter(uint64_t n_taps, double fc, std::vector<double> (*window)(int64_t))
 {
-    const std::vector<double> w = window((int64_t)n_taps);
-    std::vector<T> h(n_taps);
-    const double c = ((double)n_taps - 1.0) / 2.0;
-    for (uint64_t n = 0; n < n_taps; ++n) {
-        const double t = (double)n - c;
-        const double s = (t == 0.0) ? fc : std::sin(M_PI * fc * t) / (M_PI * t);
-        h[n] = (T)(w[n] * s);
+    // the designer lives in the library (sdr_create_fir_filter, one definition): the window functor only
+    // names the window -- the reference passes &DSP::hann_window etc.
+    int id = -1;
+    if (window == &rectangular_window) id = SDR_WIN_RECTANGULAR;
+    else if (window == &hann_window) id = SDR_WIN_HANN;
+    else if (window == &hamming_window) id = SDR_WIN_HAMMING;
+    else if (window == &blackman_window) id = SDR_WIN_BLACKMAN;
+    else if (window == &nuttall_window) id = SDR_WIN_NUTTALL;
+    else if (window == &blackman_harris_window) id = SDR_WIN_BLACKMAN_HARRIS;
+    std::vector<double> hd(n_taps);
+    if (id >= 0) {
+        sdrhip::check(sdr_create_fir_filter(n_taps, fc, id, hd.data()));
+    } else {
+        // a window of the caller's own: the library's prototype (rectangular window) times the caller's window
+        sdrhip::check(sdr_create_fir_filter(n_taps, fc, SDR_WIN_RECTANGULAR, hd.data()));
+        const std::vector<double> w = window((int64_t)n_taps);
+        for (uint64_t n = 0; n < n_taps; ++n) hd[n] *= w[n];
     }
-    return h;
+    return std::vector<T>(hd.begin(), hd.end());
 }
 }  // namespace DSP
 

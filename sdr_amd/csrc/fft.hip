@@ -505,8 +505,8 @@ int launch_fft_big(sdr_fft_plan *p, const int16_t *d_iq, float *d_out, long long
     if (need > p->cap_scr) {
         for (int i = 0; i < 2; ++i) { if (p->d_scr[i]) (void)hipFree(p->d_scr[i]); p->d_scr[i] = nullptr; }
         p->cap_scr = 0;
-        SDR_HIP(hipMalloc((void **)&p->d_scr[0], need * sizeof(cf)));
-        SDR_HIP(hipMalloc((void **)&p->d_scr[1], need * sizeof(cf)));
+        SDR_HIP(sdr::dev_malloc((void **)&p->d_scr[0], need * sizeof(cf)));
+        SDR_HIP(sdr::dev_malloc((void **)&p->d_scr[1], need * sizeof(cf)));
         p->cap_scr = need;
     }
     return run_fft_big(p, d_iq, d_out, frames, per, p->d_scr[0], p->d_scr[1], st);
@@ -608,9 +608,9 @@ extern "C" int sdr_fft_plan_create(int nfft, int hop, const double *window, sdr_
         const double a = -2.0 * M_PI * (double)i / (double)nfft;
         tw[i] = make_float2((float)cos(a), (float)sin(a));
     }
-    hipError_t e = hipMalloc((void **)&p->d_win, sizeof(float) * nfft);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw, sizeof(float2) * nfft);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_dummy, sizeof(float) * nfft);
+    hipError_t e = sdr::dev_malloc((void **)&p->d_win, sizeof(float) * nfft);
+    if (e == hipSuccess) e = sdr::dev_malloc((void **)&p->d_tw, sizeof(float2) * nfft);
+    if (e == hipSuccess) e = sdr::dev_malloc((void **)&p->d_dummy, sizeof(float) * nfft);
     if (e == hipSuccess) e = hipMemcpy(p->d_win, w.data(), sizeof(float) * nfft, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * nfft, hipMemcpyHostToDevice);
     if (e != hipSuccess) { sdr_fft_plan_destroy(p); return sdr::hip_fail(e, "fft plan upload"); }
@@ -694,13 +694,13 @@ extern "C" int sdr_fft_execute_i16_host(sdr_fft_plan *p, const int16_t *iq, size
     if (bin > p->cap_in) {
         if (p->d_in) (void)hipFree(p->d_in);
         p->d_in = nullptr; p->cap_in = 0;
-        SDR_HIP(hipMalloc(&p->d_in, bin));
+        SDR_HIP(sdr::dev_malloc(&p->d_in, bin));
         p->cap_in = bin;
     }
     if (bout > p->cap_out) {
         if (p->d_out) (void)hipFree(p->d_out);
         p->d_out = nullptr; p->cap_out = 0;
-        SDR_HIP(hipMalloc(&p->d_out, bout));
+        SDR_HIP(sdr::dev_malloc(&p->d_out, bout));
         p->cap_out = bout;
     }
     SDR_HIP(hipMemcpyAsync(p->d_in, iq, bin, hipMemcpyHostToDevice, 0));

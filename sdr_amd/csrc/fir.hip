@@ -2167,9 +2167,9 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
                 if (!p->d_i8q && !p->q_failed) {
                     const size_t qb = (size_t)sdr_fir_plan::kQueueBlocks * kI8QueueWords * sizeof(unsigned);
                     unsigned *dq = nullptr, *hd = nullptr;
-                    hipError_t ea = hipMalloc((void **)&dq, qb);
+                    hipError_t ea = sdr::dev_malloc((void **)&dq, qb);
                     if (ea == hipSuccess) ea = hipMemset(dq, 0, qb);
-                    if (ea == hipSuccess) ea = hipHostMalloc((void **)&hd, sdr_fir_plan::kQueueBlocks * sizeof(unsigned), hipHostMallocMapped);
+                    if (ea == hipSuccess) ea = sdr::host_malloc((void **)&hd, sdr_fir_plan::kQueueBlocks * sizeof(unsigned), hipHostMallocMapped);
                     if (ea == hipSuccess) {
                         std::memset(hd, 0, sdr_fir_plan::kQueueBlocks * sizeof(unsigned));
                         p->d_i8q = dq; p->h_q_done = hd;
@@ -2820,21 +2820,21 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             }
         }
     }
-    hipError_t e = hipMalloc((void **)&p->d_gtab, gt.size() * sizeof(float));
-    if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_atab8, at8.size() * sizeof(uint4));
+    hipError_t e = sdr::dev_malloc((void **)&p->d_gtab, gt.size() * sizeof(float));
+    if (e == hipSuccess && p->mfma_i8) e = sdr::dev_malloc((void **)&p->d_atab8, at8.size() * sizeof(uint4));
     if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_atab8, at8.data(), at8.size() * sizeof(uint4), hipMemcpyHostToDevice);
-    if (e == hipSuccess && p->mfma_i8) e = hipMalloc((void **)&p->d_btab8, bt8.size() * sizeof(uint4));
+    if (e == hipSuccess && p->mfma_i8) e = sdr::dev_malloc((void **)&p->d_btab8, bt8.size() * sizeof(uint4));
     if (e == hipSuccess && p->mfma_i8) e = hipMemcpy(p->d_btab8, bt8.data(), bt8.size() * sizeof(uint4), hipMemcpyHostToDevice);
-    if (e == hipSuccess && p->mfma_i8 && p->mode == SDR_MODE_FM) e = hipMalloc((void **)&p->d_ftaps, hf.size() * sizeof(float));
+    if (e == hipSuccess && p->mfma_i8 && p->mode == SDR_MODE_FM) e = sdr::dev_malloc((void **)&p->d_ftaps, hf.size() * sizeof(float));
     if (e == hipSuccess && p->d_ftaps) e = hipMemcpy(p->d_ftaps, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && p->mfma) e = hipMalloc((void **)&p->d_atab, at.size() * sizeof(float4));
+    if (e == hipSuccess && p->mfma) e = sdr::dev_malloc((void **)&p->d_atab, at.size() * sizeof(float4));
     if (e == hipSuccess && p->mfma) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_gtab, gt.data(), gt.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && chan_mix && !p->cpx) e = hipMalloc((void **)&p->d_chan_tab, chan_tab.size() * sizeof(float));
+    if (e == hipSuccess && chan_mix && !p->cpx) e = sdr::dev_malloc((void **)&p->d_chan_tab, chan_tab.size() * sizeof(float));
     if (e == hipSuccess && chan_mix && !p->cpx) e = hipMemcpy(p->d_chan_tab, chan_tab.data(), chan_tab.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && p->cpx) e = hipMalloc((void **)&p->d_chan_e, chan_e.size() * sizeof(float));
+    if (e == hipSuccess && p->cpx) e = sdr::dev_malloc((void **)&p->d_chan_e, chan_e.size() * sizeof(float));
     if (e == hipSuccess && p->cpx) e = hipMemcpy(p->d_chan_e, chan_e.data(), chan_e.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && chan_mix) e = hipMalloc((void **)&p->d_chan_fr, (size_t)p->n_chan_mix * sizeof(double));
+    if (e == hipSuccess && chan_mix) e = sdr::dev_malloc((void **)&p->d_chan_fr, (size_t)p->n_chan_mix * sizeof(double));
     if (e == hipSuccess && chan_mix) e = hipMemcpy(p->d_chan_fr, d->mix_fr_channels, (size_t)p->n_chan_mix * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         sdr_fir_plan_destroy(p);
@@ -2972,13 +2972,13 @@ extern "C" int sdr_fir_execute_host(sdr_fir_plan *p, const void *in, size_t n_in
     if (bin > p->cap_in) {
         if (p->d_in) (void)hipFree(p->d_in);
         p->d_in = nullptr; p->cap_in = 0;
-        SDR_HIP(hipMalloc(&p->d_in, bin));
+        SDR_HIP(sdr::dev_malloc(&p->d_in, bin));
         p->cap_in = bin;
     }
     if (bout > p->cap_out) {
         if (p->d_out) (void)hipFree(p->d_out);
         p->d_out = nullptr; p->cap_out = 0;
-        SDR_HIP(hipMalloc(&p->d_out, bout));
+        SDR_HIP(sdr::dev_malloc(&p->d_out, bout));
         p->cap_out = bout;
     }
     SDR_HIP(hipMemcpyAsync(p->d_in, in, bin, hipMemcpyHostToDevice, 0));

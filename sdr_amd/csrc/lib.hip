@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <atomic>
+
 #include "sdr_internal.h"
 
 namespace sdr {
@@ -106,12 +108,18 @@ extern "C" const char *sdr_strerror(int s)
 
 extern "C" const char *sdr_last_error(void) { return sdr::g_err; }
 
+namespace sdr {
+static std::atomic<unsigned long long> g_allocs{0};
+void note_alloc() { g_allocs.fetch_add(1, std::memory_order_relaxed); }
+}  // namespace sdr
+extern "C" unsigned long long sdr_alloc_count(void) { return sdr::g_allocs.load(std::memory_order_relaxed); }
+
 extern "C" int sdr_dev_alloc(void **ptr, size_t bytes)
 {
     if (!ptr) return SDR_EINVAL;
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
-    SDR_HIP(hipMalloc(ptr, bytes ? bytes : 16));
+    SDR_HIP(sdr::dev_malloc(ptr, bytes ? bytes : 16));
     return SDR_OK;
 }
 extern "C" int sdr_dev_free(void *ptr) { if (ptr) SDR_HIP(hipFree(ptr)); return SDR_OK; }

@@ -17,6 +17,13 @@ bool device_ready();          // true once the current device has been verified 
 int ensure_device();          // SDR_OK or SDR_ENODEV / SDR_EHIP
 int same_device(int plan_device);   // SDR_OK when the calling thread's current device is the plan's, else SDR_EINVAL
 
+// Every device / pinned allocation of the library goes through these two, which count: tests hold the
+// steady-state paths (a second shim call with the same filter, a block through the hand-off, the
+// allocation-free FFT entry point) to "no allocation" by the counter (sdr_alloc_count()).
+void note_alloc();
+inline hipError_t dev_malloc(void **p, size_t bytes) { note_alloc(); return hipMalloc(p, bytes); }
+inline hipError_t host_malloc(void **p, size_t bytes, unsigned flags) { note_alloc(); return hipHostMalloc(p, bytes, flags); }
+
 #define SDR_HIP(call)                                         \
     do {                                                      \
         hipError_t e_ = (call);                               \

@@ -62,10 +62,10 @@ extern "C" int sdr_fir_stream_create(sdr_fir_plan *plan, size_t max_block_sample
     const size_t max_out = win / (size_t)s->D + 2;
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
     for (int k = 0; k < kSlots && e == hipSuccess; ++k) {
-        e = hipHostMalloc(&s->h_in[k], s->max_block * in_bytes(s->input), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc(&s->d_win[k], win * in_bytes(s->input));
-        if (e == hipSuccess) e = hipMalloc(&s->d_out[k], max_out * out_bytes(s->mode));
-        if (e == hipSuccess) e = hipHostMalloc(&s->h_out[k], max_out * out_bytes(s->mode), hipHostMallocDefault);
+        e = sdr::host_malloc(&s->h_in[k], s->max_block * in_bytes(s->input), hipHostMallocDefault);
+        if (e == hipSuccess) e = sdr::dev_malloc(&s->d_win[k], win * in_bytes(s->input));
+        if (e == hipSuccess) e = sdr::dev_malloc(&s->d_out[k], max_out * out_bytes(s->mode));
+        if (e == hipSuccess) e = sdr::host_malloc(&s->h_out[k], max_out * out_bytes(s->mode), hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done[k], hipEventDisableTiming);
     }
     if (e != hipSuccess) { sdr_fir_stream_destroy(s); return sdr::hip_fail(e, "stream allocation"); }

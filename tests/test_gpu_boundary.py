@@ -64,6 +64,28 @@ def test_reference_loop_through_shims(golden, oracle, tmp_path):
     assert d.max() <= 1 and np.count_nonzero(d) <= max(4, pcm.size // 500)
 
 
+def test_shims_steady_state_allocates_nothing():
+    """the Level-1 shims keep the plans they have built (per-thread cache) and their device
+    scratch, so a second call with the same filter makes no device / pinned allocation (sdr_alloc_count
+    stands still) -- at the reference's own block sizes, 131072 samples (FM) and 1 248 000 (APT).  The
+    same calls with a fresh plan each time do allocate (the counter counts), and the hand-off allocates
+    only at stream creation."""
+    import json
+    exe = os.path.join(ROOT, "examples", "bin", "block_latency")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    by = {}
+    for row in rows:
+        by.setdefault(row["path"], []).append(row)
+    assert len(by["shim"]) == 3 and len(by["plan_per_call"]) == 2
+    for row in by["shim"] + by["stream"] + by["stream_zc"] + by["stream_pipelined"]:
+        assert row["allocations_in_steady_state"] == 0, row
+    for row in by["plan_per_call"]:
+        assert row["allocations_in_steady_state"] > 0, row
+
+
 def test_fm_loop_through_source_shim(oracle, tmp_path):
     """bladerf_fm_demod.cpp:279-313 compiled against include/sdr_hip_source.hpp + sdr_hip_shims.hpp
     (examples/fm_chain_example.cpp): SDR_BASE::build() -> start / wait_for_samples / stop over a

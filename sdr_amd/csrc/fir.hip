@@ -89,12 +89,16 @@ struct FirGeom {
     const float2 *chan_tab; // float-tile kernel: phasor tables; complex-tap matrix kernel: chan_e, one float2
                             // per channel, exp(j*2*pi*fr*D) (what one output step turns the mixer by)
     int chan_first;
+    int chan_bcast;         // 1: every channel of the launch uses table entry chan_first (one mixer for all: sdr_fir_desc.mix_fr)
     int chan_tab_stride;
     int zfix;               // fir_mfma_i8_kernel, discriminator: some tap is below the fixed-point resolution (see i8_zero_fix)
 };
 
 // kernel-side input kinds (Q-first int16 is IN_I16 with FirGeom::swap_iq)
 enum { IN_I16 = SDR_IN_I16_IQ, IN_CF32 = SDR_IN_CF32, IN_REAL = SDR_IN_F32_REAL, IN_I8 = SDR_IN_I8_IQ };
+
+// table entry of launch channel ch (channelizer plans)
+__device__ __forceinline__ long long chan_index(const FirGeom &g, long long ch) { return g.chan_bcast ? g.chan_first : g.chan_first + ch; }
 
 // LDS granule that holds sample granule sg
 __device__ __forceinline__ int lds_granule(const FirGeom &g, int sg)
@@ -571,7 +575,7 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
     float2 *ph_lo = ph_hi + g.n_ph_hi;
     const int n_tab = g.n_ph_hi + 64;            // channelizer plans: <= 2 * NT (plan creation)
     auto tab_of = [&](int tile_no) {
-        const long long c = chan ? (long long)g.chan_first + tile_no / g.tiles_per_ch : 0;
+        const long long c = chan ? chan_index(g, tile_no / g.tiles_per_ch) : 0;
         return chan ? g.chan_tab + c * g.chan_tab_stride : (const float2 *)(gtab + g.ph_off);
     };
     float2 tab_a = make_float2(0.f, 0.f), tab_b = tab_a;
@@ -596,7 +600,7 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
         __syncthreads();                         // every lane has finished with the previous tile
         float2 B = make_float2(1.f, 0.f);
         if (mixing) {
-            const double fr = chan ? g.chan_fr[g.chan_first + tr.ch] : g.mix_fr;
+            const double fr = chan ? g.chan_fr[chan_index(g, tr.ch)] : g.mix_fr;
             const double ph = fr * (double)tr.W0;
             sincospif(2.0f * (float)(ph - rint(ph)), &B.y, &B.x);
         }
@@ -1365,7 +1369,7 @@ __device__ __forceinline__ I8Chan i8_chan(const uint32_t *__restrict__ in, const
     c.src = (const unsigned char *)in + (S8 ? 2 : 4) * (ch * g.in_stride);
     c.taps = taps;
     c.lo_valid = g.lo_valid; c.hi_valid = g.hi_valid;
-    c.fr = g.chan_fr ? g.chan_fr[g.chan_first + ch] : 0.0;
+    c.fr = g.chan_fr ? g.chan_fr[chan_index(g, ch)] : 0.0;
     c.D = g.D; c.T = g.T; c.swap_iq = g.swap_iq;
     return c;
 }
@@ -1541,7 +1545,7 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
 //                  on the product (four multiply-adds per output) instead of a phasor per y; the product
 //                  of two exact zeros stays (+0, +0) (the turn's -0 is washed out by adding +0); a lane with
 //                  ONE exact zero goes through i8_zero_fix, which brings back the reference's y
-//   IQ             y itself is the output: the lane's first phasor from its phase (reduced in double), the
+//   IQ, real part  y itself is the output: the lane's first phasor from its phase (reduced in double), the
 //                  following ones by E
 template <int RH, int NCB, bool S8>
 __device__ __forceinline__ void i8_finish_cpx(const FirGeom &g, void *__restrict__ outv, const float *ybuf, int par, int F, int t,
@@ -1556,7 +1560,7 @@ __device__ __forceinline__ void i8_finish_cpx(const FirGeom &g, void *__restrict
     const long long m0 = M0 + (long long)o0;
     const long long tile_end = M0 + g.per_tile;
     const long long out_end = tile_end < g.out_end ? tile_end : g.out_end;
-    const float2 E = g.chan_tab[g.chan_first + ch];
+    const float2 E = g.chan_tab[chan_index(g, ch)];
     float2 y[RH], ynext;
     if constexpr (RH == 4) {
         const float4 qi = *(const float4 *)pa, qq = *(const float4 *)(pa + 4 * 33);
@@ -1575,17 +1579,20 @@ __device__ __forceinline__ void i8_finish_cpx(const FirGeom &g, void *__restrict
         store_values<RH>(g, outv, ch, m0, v, out_end);
         return;
     }
-    if (g.mode == SDR_MODE_IQ) {
-        const double ph = g.chan_fr[g.chan_first + ch] * (double)(m0 * g.D);
+    if (g.mode == SDR_MODE_IQ || g.mode == SDR_MODE_REAL) {
+        const double ph = g.chan_fr[chan_index(g, ch)] * (double)(m0 * g.D);
         float2 P;
         sincospif(2.0f * (float)(ph - rint(ph)), &P.y, &P.x);
         float2 *dst = (float2 *)outv + (long long)ch * g.out_stride + (m0 - g.out_begin);
+        float re[RH];
 #pragma unroll
         for (int r = 0; r < RH; ++r) {
             const float2 o = cmulf(y[r], P);
-            if (m0 + r >= g.store_from && m0 + r < out_end) nt_store((float *)(dst + r), o.x, o.y);
+            re[r] = o.x;
+            if (g.mode == SDR_MODE_IQ && m0 + r >= g.store_from && m0 + r < out_end) nt_store((float *)(dst + r), o.x, o.y);
             P = cmulf(P, E);
         }
+        if (g.mode == SDR_MODE_REAL) store_values<RH>(g, outv, ch, m0, re, out_end);
         return;
     }
     // discriminator
@@ -1775,17 +1782,17 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             if constexpr (CPX) {
                 // this tile's channel: its digits (and the low-byte bias that goes with them) become resident
                 if (work) {
-                    const int chm = i8_tile_channel(g, tile_of(p - 1));
+                    const int chm = (int)chan_index(g, i8_tile_channel(g, tile_of(p - 1)));
                     if (chm != ch_loaded) {
                         ch_loaded = chm;
-                        const uint4 *ac = atab + (size_t)(g.chan_first + chm) * (NS * NP * 4 * 64) + lane;
+                        const uint4 *ac = atab + (size_t)chm * (NS * NP * 4 * 64) + lane;
 #pragma unroll
                         for (int ks = 0; ks < NS; ++ks)
 #pragma unroll
                             for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
                                 for (int d = 0; d < 4; ++d) a[ks][pp][d] = as_i32x4(ac[((ks * NP + pp) * 4 + d) * 64]);
-                        if (!S8) bias = __builtin_bit_cast(f32x4, btab[(size_t)(g.chan_first + chm) * 64 + lane]);
+                        if (!S8) bias = __builtin_bit_cast(f32x4, btab[(size_t)chm * 64 + lane]);
                     }
                 }
             }
@@ -2065,6 +2072,7 @@ struct sdr_fir_plan {
     float *d_gtab = nullptr;
     // channelizer: per-channel NCO frequencies (double) and phasor tables (float2, tab_stride per channel)
     int n_chan_mix = 0;
+    bool chan_bcast = false;    // one mixer (sdr_fir_desc.mix_fr) kept as a one-entry channel table that every channel uses
     double *d_chan_fr = nullptr;
     float2 *d_chan_tab = nullptr;
     int chan_tab_stride = 0;
@@ -2312,9 +2320,10 @@ int launch(sdr_fir_plan *p, const void *in, long long in_first, long long n_resi
     g.swap_iq = (p->input == SDR_IN_I16_QI) ? 1 : 0;
     g.ph_off = p->ph_off; g.n_ph_hi = p->n_ph_hi;
     g.zfix = (p->mfma_i8 && p->mode == SDR_MODE_FM && p->zfix) ? 1 : 0;
-    g.chan_fr = nullptr; g.chan_tab = nullptr; g.chan_first = 0; g.chan_tab_stride = 0;
+    g.chan_fr = nullptr; g.chan_tab = nullptr; g.chan_first = 0; g.chan_tab_stride = 0; g.chan_bcast = p->chan_bcast ? 1 : 0;
+    if (p->chan_bcast) chan_first = 0;
     if (p->n_chan_mix > 0) {
-        if (chan_first < 0 || chan_first + (long long)n_ch > p->n_chan_mix) {
+        if (!p->chan_bcast && (chan_first < 0 || chan_first + (long long)n_ch > p->n_chan_mix)) {
             sdr::set_error("channels [%lld, %lld) but the plan has %d channel mixers", chan_first, chan_first + (long long)n_ch, p->n_chan_mix);
             return SDR_EINVAL;
         }
@@ -2372,6 +2381,27 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
 
+    // One mixer on integer input (frequency_shift in front of the filter): when the window fits
+    // the complex-tap matrix kernel (256 samples), the plan is built as a channelizer whose one table entry
+    // every channel uses -- 0.31 against 0.55 ms per 2^28 samples at 64 taps / 10 on the float-tile kernel,
+    // and exact integer sums, so shards and blocks reproduce the one-piece result bit for bit.
+    if (d && out && d->mix_fr != 0.0 && d->n_mix_channels == 0 && (d->pipeline == 0 || d->pipeline == 5) && !d->outputs_per_lane &&
+        !d->threads && d->taps && d->decim > 0 && d->n_taps >= 6 && d->n_taps <= 256 &&
+        (d->input == SDR_IN_I16_IQ || d->input == SDR_IN_I16_QI || d->input == SDR_IN_I8_IQ) &&
+        (d->n_taps - 1 + 3) / 4 * 4 + 15 * d->decim + 1 <= 256 && (d->size_hint == 0 || d->size_hint >= (1LL << 22))) {
+        sdr_fir_desc dd = *d;
+        const double fr1 = d->mix_fr;
+        dd.mix_fr = 0.0; dd.n_mix_channels = 1; dd.mix_fr_channels = &fr1; dd.pipeline = 5;
+        sdr_fir_plan *q = nullptr;
+        if (sdr_fir_plan_create(&dd, &q) == SDR_OK && q) {
+            q->chan_bcast = true;
+            q->mix_fr = d->mix_fr;
+            if (q->tiny) { q->tiny->chan_bcast = true; q->tiny->mix_fr = d->mix_fr; }
+            *out = q;
+            return SDR_OK;
+        }
+        if (d->pipeline == 5) return SDR_EINVAL;       // (the explicit choice does not fit: the error text is set)
+    }
     const bool chan_mix = d->n_mix_channels > 0;
     if (d->n_mix_channels < 0 || (chan_mix && !d->mix_fr_channels)) { sdr::set_error("n_mix_channels without mix_fr_channels"); return SDR_EINVAL; }
     if (chan_mix && d->mix_fr != 0.0) { sdr::set_error("mix_fr and mix_fr_channels are alternatives"); return SDR_EINVAL; }
@@ -2840,7 +2870,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         sdr_fir_plan_destroy(p);
         return sdr::hip_fail(e, "plan upload");
     }
-    if (p->mfma_i8 && d->pipeline == 0) {
+    if (p->mfma_i8 && (d->pipeline == 0 || p->cpx)) {
         sdr_fir_desc d2 = *d;
         d2.pipeline = (d->input == SDR_IN_I8_IQ || chan_mix) ? 2 : 1;        // float tiles | raw tile
         if (sdr_fir_plan_create(&d2, &p->tiny) != SDR_OK) p->tiny = nullptr;
@@ -2950,7 +2980,7 @@ extern "C" int sdr_fir_execute_channels_dev(sdr_fir_plan *p, const void *d_in, s
                                             void *stream)
 {
     if (!p || !d_in || !d_out) { sdr::set_error("null argument"); return SDR_EINVAL; }
-    if (p->n_chan_mix <= 0) { sdr::set_error("the plan has no per-channel mixers (sdr_fir_desc.n_mix_channels)"); return SDR_EINVAL; }
+    if (p->n_chan_mix <= 0 || p->chan_bcast) { sdr::set_error("the plan has no per-channel mixers (sdr_fir_desc.n_mix_channels)"); return SDR_EINVAL; }
     const long long cnt = out_count(p, (long long)n_in);
     // in_stride 0: every channel reads the same wideband buffer
     if (n_channels > 1 && ((in_stride != 0 && in_stride < n_in) || out_stride < (size_t)cnt)) { sdr::set_error("channel stride smaller than channel length"); return SDR_EINVAL; }

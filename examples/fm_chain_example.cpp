@@ -83,8 +83,12 @@ int main(int argc, char** argv)
         sdrhip::REPLAY_SDR* replay = dynamic_cast<sdrhip::REPLAY_SDR*>(sdr.get());
         uint64_t blocks = 0;
         while (1) {                                                               // :281
-            sdr->wait_for_samples();                                              // :284
-            if (replay->finished()) break;                                        // a recording ends; a radio does not
+            try {
+                sdr->wait_for_samples();                                          // :284
+            } catch (const sdrhip::REPLAY_SDR::end_of_stream&) {
+                break;                                                            // a recording ends; a radio does not
+            }
+            if (cf_samples.empty()) break;
             // :288-298
             std::vector<float> x5 = sdrhip::af_fir_pick_discriminate(cf_samples, lpf, (int)dec_rate, phasor_scale);
             // :301-313

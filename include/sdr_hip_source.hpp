@@ -25,6 +25,7 @@
 #define SDR_HIP_SOURCE_HPP_
 
 #include <atomic>
+#include <exception>
 #include <cmath>
 #include <complex>
 #include <condition_variable>
@@ -155,6 +156,9 @@ public:
     // bladerf_sdr.h:305-319
     void start(std::vector<std::complex<float>>& cf_samples) override
     {
+        stop();                                      // a second start() without stop(): end the running producer first
+        cf_out_ = &cf_samples;
+        error_ = nullptr;
         collect_samples = true;
         processed = false;
         finished_ = false;
@@ -188,14 +192,26 @@ public:
     }
 
     // sdr_base.h:50-55, plus: coming back here tells the producer that the previous block has been
-    // consumed, and a finished source releases the waiter (check finished() afterwards)
+    // consumed.  A radio never ends; a recording does, and the producer can fail.  The reference's loops
+    // are `while (run) { wait_for_samples(); process(cf_samples); }` and know neither case, so both are
+    // made visible through what such a loop already has: a producer error is rethrown here (the mains
+    // wrap the loop in try / catch (std::exception), bladerf_apt_demod.cpp:857), and at the end of the
+    // source cf_samples comes back EMPTY (not the previous block once more) -- and, unless
+    // set_throw_at_end(false), sdrhip::end_of_stream (a std::runtime_error) is thrown.
+    struct end_of_stream : std::runtime_error { end_of_stream() : std::runtime_error("replay source exhausted") {} };
+    void set_throw_at_end(bool on) { throw_at_end_ = on; }
     void wait_for_samples() override
     {
         std::unique_lock<std::mutex> lck(sdr_mtx);
         consumed_ = true;
         sdr_cv.notify_all();
         sdr_cv.wait(lck, [this] { return processed || finished_; });
+        const bool fresh = processed;
         processed = false;
+        if (fresh) return;
+        if (cf_out_) cf_out_->clear();
+        if (error_) std::rethrow_exception(error_);
+        if (throw_at_end_) throw end_of_stream();
     }
 
     bool finished() const { return finished_; }
@@ -207,10 +223,12 @@ private:
     void convert(const std::complex<int16_t>* in, size_t n, std::complex<float>* out)
     {
         // bladerf_sdr.h:288-291 on the GPU: cf = complex<float>(re, im) * (1/2048)
-        DevMem d_i(n * 4), d_f(n * 8);
-        check(sdr_dev_upload(d_i.get(), in, n * 4));
-        check(sdr_unpack_i16_dev(d_i.as<int16_t>(), n, d_f.as<float>(), nullptr));
-        check(sdr_dev_download(out, d_f.get(), n * 8));
+        // (the calling thread's grow-only device scratch: no allocation per block)
+        int16_t* d_i = static_cast<int16_t*>(scratch().get(0, n * 4));
+        float* d_f = static_cast<float*>(scratch().get(1, n * 8));
+        check(sdr_dev_upload(d_i, in, n * 4));
+        check(sdr_unpack_i16_dev(d_i, n, d_f, nullptr));
+        check(sdr_dev_download(out, d_f, n * 8));
     }
 
     // bladerf_sdr.h:270-302
@@ -244,6 +262,7 @@ private:
         } catch (const std::exception& e) {
             std::fprintf(stderr, "error in collection thread: %s\n", e.what());    // bladerf_sdr.h:298-301
             std::lock_guard<std::mutex> lg(sdr_mtx);
+            error_ = std::current_exception();       // handed to the consumer by wait_for_samples()
             finished_ = true;
             sdr_cv.notify_all();
         }
@@ -255,6 +274,9 @@ private:
     std::thread thread_;
     std::vector<std::complex<int16_t>> raw_;
     bool consumed_ = true;
+    bool throw_at_end_ = true;
+    std::vector<std::complex<float>>* cf_out_ = nullptr;
+    std::exception_ptr error_;
     std::atomic<bool> finished_{false};
     uint64_t blocks_ = 0;
 };

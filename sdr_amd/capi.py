@@ -11,7 +11,17 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SDRHIP_LIB") or os.path.join(_HERE, "libsdrhip.so")   # override: kernel experiments
+LIB_PATH = os.path.join(_HERE, "libsdrhip.so")
+# A/B measurements of experiment builds (tools/ab_libs.py) bind another build -- only from inside sdr_amd/
+# (a stray environment variable cannot make a foreign library stand in for the product), and loudly
+if os.environ.get("SDRHIP_LIB"):
+    _alt = os.path.abspath(os.environ["SDRHIP_LIB"])
+    if os.path.dirname(_alt).startswith(_HERE) and os.path.basename(_alt).startswith("libsdrhip"):
+        import sys as _sys
+        print(f"sdr_amd: SDRHIP_LIB -> {_alt} (experiment build, not the product library)", file=_sys.stderr)
+        LIB_PATH = _alt
+    else:
+        raise ImportError(f"SDRHIP_LIB={_alt}: only builds under {_HERE} named libsdrhip*.so can be bound")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "fft_wave.hip", "stream.hip", "apt.hip", "lib.hip")]
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
@@ -323,7 +333,8 @@ class FftPlan:
         return lib().sdr_fft_frame_count(self.h, n_in)
 
     def set_variant(self, variant):
-        """0 auto, 1 workgroup exchange, 2 two frames per lane, 3 one frame per wavefront"""
+        """0 auto, 1 workgroup exchange, 2 two frames per lane, 3 one frame per wavefront (4 waves per CU),
+        4 one frame per wavefront with 8 waves per CU (what the automatic choice runs)"""
         check(lib().sdr_fft_plan_set_variant(self.h, C.c_int(variant)))
 
     def execute_host(self, iq):

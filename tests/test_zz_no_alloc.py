@@ -54,6 +54,53 @@ def test_noalloc_equals_allocating_entry_point(sdr, oracle, nfft, hop):
     assert np.abs(lin - want_lin).max() <= 1e-5 * want_lin.max()
 
 
+def test_noalloc_makes_no_allocation_and_runs_under_capture(sdr, oracle):
+    """nothing detected an allocation on the no-alloc path.  Two detectors: the library's own
+    allocation counter stands still across the call (and moves for the allocating entry point's first
+    long-frame call on a fresh plan), and the call is captured into a HIP graph -- hipMalloc is not
+    permitted on a capturing stream -- whose replay gives the same bits."""
+    import ctypes as C
+    L = sdr.capi.lib()
+    L.sdr_alloc_count.restype = C.c_ulonglong
+    nfft, hop = 16384, 16384
+    n = 3 * nfft + 11
+    iq = oracle.synth_fm_i16(n, fs=61.44e6, ftone=250e3, dev=2.0e6, amp=1200.0)
+    d_iq = sdr.DevBuf.from_numpy(iq)
+    plan = sdr.FftPlan(nfft, hop, sdr.window("blackman", nfft))
+    frames = plan.frame_count(n)
+    d_a, d_b, d_c = (sdr.DevBuf(frames * nfft * 4) for _ in range(3))
+    a0 = L.sdr_alloc_count()
+    assert plan.execute_noalloc_dev(d_iq, n, d_a, frames) == frames
+    sdr.sync()
+    assert L.sdr_alloc_count() == a0
+    assert plan.execute_dev(d_iq, n, d_b, frames) == frames        # grows the plan's scratch: counted
+    sdr.sync()
+    assert L.sdr_alloc_count() > a0
+    a = d_a.to_numpy(np.float32, frames * nfft)
+    assert a.tobytes() == d_b.to_numpy(np.float32, frames * nfft).tobytes()
+    # under stream capture
+    hip = C.CDLL("libamdhip64.so")
+    st, graph, gexec = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    try:
+        assert hip.hipStreamBeginCapture(st, C.c_int(0)) == 0      # hipStreamCaptureModeGlobal
+        try:
+            assert plan.execute_noalloc_dev(d_iq, n, d_c, frames, stream=st.value) == frames
+        finally:
+            rc = hip.hipStreamEndCapture(st, C.byref(graph))
+        assert rc == 0 and graph.value
+        assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)) == 0
+        assert hip.hipGraphLaunch(gexec, st) == 0
+        assert hip.hipStreamSynchronize(st) == 0
+        assert d_c.to_numpy(np.float32, frames * nfft).tobytes() == a.tobytes()
+    finally:
+        if gexec.value:
+            hip.hipGraphExecDestroy(gexec)
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+        hip.hipStreamDestroy(st)
+
+
 def test_noalloc_limits_and_errors(sdr):
     big = sdr.FftPlan(262144, 262144)
     d_iq, d_out = sdr.DevBuf(262144 * 4), sdr.DevBuf(262144 * 4)

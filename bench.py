@@ -390,7 +390,9 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("fir_bytes_per_launch")
-                traffic_source = "profiles/hbm_traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, not this run")
+                traffic_source = "profiles/hbm_traffic.json, counter run of commit %s, profile tag %s (%s)" % (
+                    tj.get("commit", "?"), tj.get("profile_tag", "?"),
+                    tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, not this run"))
             except Exception:
                 traffic = None
         line = {

@@ -61,7 +61,13 @@ def main():
             for row in csv.DictReader(f):
                 if row["Name"] == k:
                     avg_ns = float(row["AverageNs"])
-        json.dump({"fir_bytes_per_launch": int(fb + wb), "fetch_bytes_corrected_x2": int(fb), "write_bytes": int(wb),
+        import subprocess
+        try:
+            head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+            dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "sdr_amd", "bench.py"], text=True).strip())
+        except Exception:
+            head, dirty = None, None
+        json.dump({"fir_bytes_per_launch": int(fb + wb), "commit": head, "sources_modified_since_commit": dirty, "fetch_bytes_corrected_x2": int(fb), "write_bytes": int(wb),
                    "kernel": k, "rocprof_avg_kernel_ns": avg_ns, "profile_tag": tag,
                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python3 bench.py, mean over "
                              "the kernel's dispatches; FETCH_SIZE doubled per the guide's gfx950 correction; KB -> bytes x1024"},

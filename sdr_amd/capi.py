@@ -22,7 +22,7 @@ if os.environ.get("SDRHIP_LIB"):
         LIB_PATH = _alt
     else:
         raise ImportError(f"SDRHIP_LIB={_alt}: only builds under {_HERE} named libsdrhip*.so can be bound")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir.hip", "fft.hip", "fft_wave.hip", "stream.hip", "apt.hip", "lib.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fir_mfma_i8.hip", "fir_tiles.hip", "fir_plan.hip", "fft.hip", "fft_wave.hip", "stream.hip", "apt.hip", "lib.hip")]
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 OK, EINVAL, ENOMEM, EHIP, EALIGN, ECAPACITY, ENODEV, ERANGE = range(8)
@@ -52,11 +52,11 @@ class FirDesc(C.Structure):
 # the register pairs); the FIR walk gains from v_pk_fma_f32 and keeps the default
 # fft_wave.hip (one 4096-point frame per wavefront) is bound by vector-instruction issue: the max-ILP
 # scheduling strategy leaves fewer dependent-issue stalls there (0.723 vs 0.734 ms per 2^28 samples)
-# fir.hip: the int8 matrix kernel draws its tiles from an atomic counter one phase ahead; LLVM's atomic
+# fir_mfma_i8.hip: the int8 matrix kernel draws its tiles from an atomic counter one phase ahead; LLVM's atomic
 # optimizer would rewrite that one-lane atomic into a wave-wide form that reads the result back at once
 # (s_waitcnt vmcnt(0) right behind the atomic: the round trip, and the acknowledgements of the stores
 # before it, in every phase).  Results do not depend on the flag, only the kernel's speed.
-EXTRA_FLAGS = {"fir.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+EXTRA_FLAGS = {"fir_mfma_i8.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
                "fft.hip": ["-fno-slp-vectorize"],
                "fft_wave.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
@@ -65,6 +65,7 @@ def build(force=False):
     """hipcc -> sdr_amd/libsdrhip.so (cross-compiles for gfx950 without a GPU)."""
     srcs = [s for s in SOURCES if os.path.exists(s)]
     deps = srcs + [os.path.join(_HERE, "csrc", "sdr_internal.h"), os.path.join(_HERE, "csrc", "fft_common.h"),
+                   os.path.join(_HERE, "csrc", "fir_common.h"),
                    os.path.join(INCLUDE, "sdr_hip.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):

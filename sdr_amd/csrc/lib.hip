@@ -81,7 +81,7 @@ extern "C" const char *sdr_build_info(void)
     const int fir = sdr::measurement_flags_fir(), fft = sdr::measurement_flags_fft(), fftw = sdr::measurement_flags_fft_wave();
     if (!fir && !fft && !fftw) return "libsdrhip product build (gfx950)";
     snprintf(text, sizeof(text), "libsdrhip MEASUREMENT BUILD -- results are wrong by construction "
-             "(ablation masks: fir.hip %d, fft.hip %d, fft_wave.hip %d; -1 = built with SDR_MEASUREMENT_BUILD, no mask)", fir, fft, fftw);
+             "(ablation masks: fir_mfma_i8.hip %d, fft.hip %d, fft_wave.hip %d; -1 = built with SDR_MEASUREMENT_BUILD, no mask)", fir, fft, fftw);
     return text;
 }
 

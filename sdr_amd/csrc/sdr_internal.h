@@ -30,7 +30,7 @@ inline hipError_t host_malloc(void **p, size_t bytes, unsigned flags) { note_all
         if (e_ != hipSuccess) return ::sdr::hip_fail(e_, #call); \
     } while (0)
 
-// Measurement switches (SDR_I8_ABLATE in fir.hip; SDR_FFT_ABLATE, SDR_FFT_PADLDS, SDR_FFT_MINB in
+// Measurement switches (SDR_I8_ABLATE in fir_mfma_i8.hip; SDR_FFT_ABLATE, SDR_FFT_PADLDS, SDR_FFT_MINB in
 // fft.hip) compile parts of a kernel out to time the rest: their results are wrong by construction.
 // They are honoured only under -DSDR_MEASUREMENT_BUILD, which capi.build() never sets, and a
 // library that contains such a translation unit says so: sdr_build_info() names it and sdr_init()
@@ -41,7 +41,7 @@ inline hipError_t host_malloc(void **p, size_t bytes, unsigned flags) { note_all
 #endif
 #endif
 int fft_static_scratch_init(void **ptr_out);   // fft.hip: address of the no-alloc scratch on the current device
-int measurement_flags_fir();  // 0 in the product; the ablation mask of fir.hip in a measurement build (-1: none set)
+int measurement_flags_fir();  // 0 in the product; the ablation mask of fir_mfma_i8.hip in a measurement build (-1: none set)
 int measurement_flags_fft();  // the same for fft.hip
 int measurement_flags_fft_wave();  // and for fft_wave.hip
 

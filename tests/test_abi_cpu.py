@@ -72,6 +72,25 @@ def test_no_cpu_fallback(capi):
     assert e.value.status in (capi.ENODEV, capi.EHIP)
 
 
+def test_product_sources_never_reference_the_oracle():
+    """the product path (sdr_amd/, include/) must not import, load or link the CPU checker: no mention of
+    oracle/, its libraries or dlopen in any shipped source (only tests/, smoke() and bench.py's cpu legs may)"""
+    import re
+    bad = []
+    pat = re.compile(r"oracle|liboracle|libsdrref|dlopen|LoadLibrary", re.I)
+    for top in ("sdr_amd", "include"):
+        for dirpath, dirnames, files in os.walk(os.path.join(ROOT, top)):
+            dirnames[:] = [d for d in dirnames if d not in ("build", "__pycache__")]
+            for f in files:
+                if not f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")):
+                    continue
+                path = os.path.join(dirpath, f)
+                for i, line in enumerate(open(path, errors="replace"), 1):
+                    if pat.search(line):
+                        bad.append(f"{os.path.relpath(path, ROOT)}:{i}: {line.strip()[:100]}")
+    assert not bad, "product sources mention the oracle:\n" + "\n".join(bad)
+
+
 def test_product_build_is_not_a_measurement_build(capi):
     """kernel ablation switches exist only behind -DSDR_MEASUREMENT_BUILD, which capi.build() never sets"""
     assert capi.build_info().startswith("libsdrhip product build")

@@ -1,4 +1,4 @@
-"""CPU model of the arithmetic behind FIR plan pipeline 5 (fir_mfma_i8_kernel, sdr_amd/csrc/fir.hip):
+"""CPU model of the arithmetic behind FIR plan pipeline 5 (fir_mfma_i8_kernel, sdr_amd/csrc/fir_mfma_i8.hip):
 int16 samples as two signed bytes, taps as four balanced base-256 digits of a 31-bit fixed-point
 value, seven of the eight byte products (the weight-2^0 one is below 2^-30 of full scale and left out)
 in four exact integer accumulators per output over the whole window, one float32 combination.  The kernel itself is

@@ -1,4 +1,4 @@
-"""CPU models of the two mixer formulations the float-tile kernel uses (sdr_amd/csrc/fir.hip,
+"""CPU models of the two mixer formulations the float-tile kernel uses (sdr_amd/csrc/fir_tiles.hip,
 fir_stream_kernel), checked against the reference's order of operations -- frequency_shift then
 polyphase_decimate (bladerf_apt_demod.cpp:744-748) -- as the oracle restates it.  No GPU."""
 import numpy as np

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Register / scratch use of every kernel of one translation unit as hipcc reports it
 (-Rpass-analysis=kernel-resource-usage), with the per-file flags of sdr_amd/capi.py.
-usage: tools/kernel_resources.py sdr_amd/csrc/fir.hip [filter-substring] [-- extra hipcc flags]"""
+usage: tools/kernel_resources.py sdr_amd/csrc/fir_mfma_i8.hip [filter-substring] [-- extra hipcc flags]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -56,7 +56,15 @@ class FirDesc(C.Structure):
 # optimizer would rewrite that one-lane atomic into a wave-wide form that reads the result back at once
 # (s_waitcnt vmcnt(0) right behind the atomic: the round trip, and the acknowledgements of the stores
 # before it, in every phase).  Results do not depend on the flag, only the kernel's speed.
-EXTRA_FLAGS = {"fir_mfma_i8.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+# fir_mfma_i8.hip, -fno-slp-vectorize: REQUIRED FOR CORRECT RESULTS, not a tuning flag.  With the SLP vectoriser on,
+# hipcc (ROCm 7.2) turns the helper waves' discriminator arithmetic into packed float32 instructions (v_pk_mul_f32 /
+# v_pk_fma_f32), and on MI355X the LOW half of those results came out wrong in lanes 48-63 -- intermittently, and only
+# while the matrix wave of the same SIMD was inside its MFMA loop (short phases: D = 1, 2; several tiles per workgroup;
+# up to 97 % of launches at 7 taps / 1 on 1.2 M samples; tests/test_gpu_parity.py::test_matrix_kernel_many_short_tiles).
+# Without packed float32 in that file the failure is gone (and packed float32 cannot issue in the shadow of another
+# wave's MFMAs anyway).  An isolated reproduction (tools/ubench/pk_under_mfma.hip) did not show it, so
+# the trigger is narrower than "packed float32 beside MFMA"; DESIGN 3.4 records what is known.
+EXTRA_FLAGS = {"fir_mfma_i8.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
                "fft.hip": ["-fno-slp-vectorize"],
                "fft_wave.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
@@ -214,7 +222,7 @@ class FirPlan:
         r, nt, lds = C.c_int(), C.c_int(), C.c_int()
         check(lib().sdr_fir_plan_info(self.h, C.byref(r), C.byref(nt), C.byref(lds)))
         return {"outputs_per_lane": r.value, "threads": nt.value, "lds_bytes": lds.value,
-                "kernel": {1: "raw_tile", 2: "stream", 3: "planar", 4: "mfma", 5: "mfma_i8", 6: "ksplit"}.get(lib().sdr_fir_plan_kernel(self.h), "?")}
+                "kernel": {1: "raw_tile", 2: "stream", 3: "planar", 4: "mfma", 5: "mfma_i8", 6: "ksplit", 7: "float_dma_tile"}.get(lib().sdr_fir_plan_kernel(self.h), "?")}
 
     def out_count(self, n_in):
         return lib().sdr_fir_out_count(self.h, n_in)

@@ -71,6 +71,7 @@ struct sdr_fir_plan {
     int input, mode, D, T, R, NT;
     int count_rule = SDR_COUNT_FLOOR;   // sdr_count_rule
     bool raw;               // raw-tile geometry (4 samples per granule): fir_raw_kernel or fir_planar_kernel
+    bool rawf = false;      // fir_raw_kernel on FLOAT tiles (complex / real float input without mixer): raw is set too
     bool planar = false;    // fir_planar_kernel (float planes, convert once)
     bool mfma = false;      // fir_mfma_kernel (float planes, Toeplitz GEMM on the matrix cores)
     float4 *d_atab = nullptr;   // its A-operand table

@@ -140,7 +140,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->n_taps > 16384) { sdr::set_error("n_taps > 16384 unsupported"); return SDR_EINVAL; }
     if (d->input < SDR_IN_I16_IQ || d->input > SDR_IN_I8_IQ) { sdr::set_error("bad input kind"); return SDR_EINVAL; }
     if (d->mode < SDR_MODE_IQ || d->mode > SDR_MODE_REAL) { sdr::set_error("bad mode"); return SDR_EINVAL; }
-    if (d->pipeline < 0 || d->pipeline > 6) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
+    if (d->pipeline < 0 || d->pipeline > 7) { sdr::set_error("bad pipeline"); return SDR_EINVAL; }
     if (d->count_rule != SDR_COUNT_FLOOR && d->count_rule != SDR_COUNT_AF_SEQ) { sdr::set_error("bad count_rule"); return SDR_EINVAL; }
     int rc = sdr::ensure_device();
     if (rc != SDR_OK) return rc;
@@ -184,6 +184,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if ((d->pipeline == 1 || d->pipeline == 3 || d->pipeline == 4) && !raw_possible) { delete p; sdr::set_error("pipelines 1, 3 and 4 need int16 input without mixer"); return SDR_EINVAL; }
     if (d->pipeline == 5 && !i8_possible) { delete p; sdr::set_error("pipeline 5 needs int16 or int8 input without mixer"); return SDR_EINVAL; }
     const bool ksplit_possible = d->input == SDR_IN_F32_REAL && d->mode != SDR_MODE_FM;
+    // float input without mixer: the DMA'd image is the float tile (fir_raw_kernel<R, IN_CF32 | IN_REAL>)
+    const bool rawf_possible = (d->input == SDR_IN_CF32 || d->input == SDR_IN_F32_REAL) && d->mix_fr == 0.0 && !chan_mix;
+    if (d->pipeline == 7 && !rawf_possible) { delete p; sdr::set_error("pipeline 7 needs complex or real float input without mixer"); return SDR_EINVAL; }
     if (d->pipeline == 6 && !ksplit_possible) { delete p; sdr::set_error("pipeline 6 needs real float input and a mode other than FM"); return SDR_EINVAL; }
     // The planar kernel (float planes, convert once) is an explicit choice only: beyond the int8
     // matrix kernel's window it is 8-12 % ahead of the raw tile at D = 8 and 10 but 1.4-1.8x behind
@@ -384,6 +387,40 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             }
         }
     }
+    // Float input without mixer: the DMA-filled tile kernel (fir_raw_kernel<R, IN_CF32 | IN_REAL>), explicitly
+    // (pipeline 7) or automatically.  From tools/sweep_float_dma.py (twelve shapes, T = 32..511, D = 2..20, all nine
+    // R x workgroup geometries, 2^27 samples): complex float runs 1.4-2.2x the persistent float-tile kernel on every
+    // shape (64 taps / 10: 3.9 -> 5.6 TB/s) with the SMALLEST number of outputs per lane that gives a lane ten
+    // samples of its own -- nothing is converted, so sharing a loaded sample between outputs saves LDS reads only,
+    // and wide lanes cost tile bytes; real float gains 12-77 % with four outputs per lane on long windows (the walk
+    // is bound by LDS reads there) and the smallest lane of sixteen samples on short ones, and loses 10-15 % where
+    // the lane stride exceeds ten granules (D = 15: 195 and 511 taps), which stay on the float-tile kernel.
+    if (!bestR && rawf_possible && (d->pipeline == 7 || (d->pipeline == 0 && !d->outputs_per_lane && !d->threads))) {
+        const bool cf = d->input == SDR_IN_CF32;
+        const int spg = cf ? 2 : 4;
+        const bool pinned = d->pipeline == 7;
+        int R = 0;
+        if (d->outputs_per_lane) R = d->outputs_per_lane;
+        else {
+            const int own = cf ? 10 : 16;                      // samples a lane should own
+            const bool long_real = !cf && p->T >= 16 * p->D;
+            for (int ri = (long_real ? 2 : 0); ri < 3 && !R; ++ri)
+                if ((p->D * Rs[ri]) % spg == 0 && (p->D * Rs[ri] >= own || ri == 2)) R = Rs[ri];
+            for (int ri = 2; ri >= 0 && !R; --ri)
+                if ((p->D * Rs[ri]) % spg == 0) R = Rs[ri];
+        }
+        const bool wanted = pinned || (R && (cf || p->D * R <= 40));
+        for (int ni = 0; ni < 3 && R && wanted && !bestR; ++ni) {
+            const int NT = NTs[ni];
+            if (d->threads && d->threads != NT) continue;
+            Geometry gm;
+            if (!make_geometry(p->T, p->D, R, NT, spg, false, &gm)) break;
+            // automatic choice: two workgroups per CU at least (tiles up to 80 KB); pinned: anything the LDS holds
+            if (gm.lds_bytes > ((pinned && (d->threads || ni == 2)) ? 160 * 1024 : 80 * 1024)) continue;
+            best = gm; bestR = R; bestNT = NT; best_raw = true; p->rawf = true;
+        }
+        if (!bestR && pinned) { delete p; sdr::set_error("pipeline 7: no tile geometry for decim=%d taps=%d (outputs_per_lane=%d threads=%d)", d->decim, d->n_taps, d->outputs_per_lane, d->threads); return SDR_EINVAL; }
+    }
     // second pass: shapes that fit no preferred tile (large decimation factors, very long filters)
     // take any tile the LDS holds, and more granules per lane than the kernel prefetches
     for (int pass = 0; pass < 2 && !bestR; ++pass) {
@@ -433,7 +470,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                        d->decim, d->n_taps, d->outputs_per_lane, d->threads, d->pipeline);
         return SDR_EINVAL;
     }
-    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma && !p->mfma_i8; p->spg = (best_raw || p->input == SDR_IN_F32_REAL) ? 4 : 2;
+    p->R = bestR; p->NT = bestNT; p->raw = best_raw; p->planar = best_raw && planar && !p->mfma && !p->mfma_i8; p->spg = ((best_raw && !p->rawf) || p->input == SDR_IN_F32_REAL) ? 4 : 2;
     p->Tback = best.Tback; p->Lw4 = best.Lw4; p->ngran = best.ngran; p->q = best.q; p->pad = best.pad;
     p->s_gran = best.s_gran; p->a_gran = best.a_gran; p->n_inst = best.n_inst; p->lds_bytes = best.lds_bytes;
     {
@@ -458,7 +495,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     // gtab[j][r] = h[D*r + Tback - j]  (tap that window offset j contributes to output r);
     // rows past the window (padding + look-ahead step) stay zero
     const size_t rows = (size_t)(best.ngran + best.look) * p->spg;
-    const bool real_tile = !p->raw && p->input == SDR_IN_F32_REAL;
+    const bool real_tile = (!p->raw || p->rawf) && p->input == SDR_IN_F32_REAL;
     std::vector<float> gt(rows * p->R * (real_tile ? 2 : 1), 0.0f);
     for (size_t j = 0; j < rows; ++j)
         for (int r = 0; r < p->R; ++r) {
@@ -689,7 +726,7 @@ extern "C" int sdr_fir_plan_shape(const sdr_fir_plan *p, int *input, int *mode, 
 
 extern "C" int sdr_fir_plan_kernel(const sdr_fir_plan *p)
 {
-    return p ? (p->ksplit ? 6 : (p->mfma_i8 ? 5 : (p->mfma ? 4 : (p->planar ? 3 : (p->raw ? 1 : 2))))) : 0;
+    return p ? (p->ksplit ? 6 : (p->mfma_i8 ? 5 : (p->mfma ? 4 : (p->planar ? 3 : (p->rawf ? 7 : (p->raw ? 1 : 2)))))) : 0;
 }
 
 extern "C" int sdr_fir_execute_dev(sdr_fir_plan *p, const void *d_in, size_t n_in, void *d_out,

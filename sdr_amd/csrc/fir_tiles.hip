@@ -383,11 +383,17 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)p;
 }
 
-template <int R>
+// IN = IN_I16: raw int16 pairs, converted after each LDS read (the kernel described above).
+// IN = IN_CF32 / IN_REAL (plan `pipeline` = 7): float input without mixer needs no conversion at all, so the
+// DMA'd image IS the float tile the walk reads (two complex or four real samples per 16-byte granule) --
+// no register prefetch, no LDS stores, one tile per workgroup under the hardware dispatcher.
+template <int R, int IN>
 __global__ void __launch_bounds__(256)
-fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
+fir_raw_kernel(const void *__restrict__ in, void *__restrict__ outv,
                const float *__restrict__ gtab, const FirGeom g)
 {
+    constexpr int SPG = (IN == IN_CF32) ? 2 : 4;             // samples per 16-byte granule
+    constexpr int ESZ = (IN == IN_CF32) ? 8 : 4;             // bytes per sample
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *lds4 = (uint4 *)smem;
     const int tid = threadIdx.x;
@@ -397,37 +403,44 @@ fir_raw_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     if (tile >= g.tiles_per_ch) return;
     const long long M0 = g.tile0 + (long long)tile * g.per_tile;
     const long long W0 = M0 * g.D - g.Tback;                 // first staged sample (multiple of 4)
-    const uint32_t *src = in + ch * g.in_stride;             // sample 0 of this channel
+    const unsigned char *src = (const unsigned char *)in + ch * g.in_stride * ESZ;   // sample 0 of this channel
 
-    const bool interior = (W0 >= g.lo_valid) && (W0 + 4LL * g.s_gran <= g.hi_valid);
+    const bool interior = (W0 >= g.lo_valid) && (W0 + (long long)SPG * g.s_gran <= g.hi_valid);
     if (interior) {
-        const uint32_t *wsrc = src + W0;
+        const unsigned char *wsrc = src + W0 * ESZ;
         for (int k = 0; k < g.n_inst; ++k) {
             const int a = k * NT + tid;
             int sg = sample_granule(g, a);
             sg = sg < g.s_gran ? sg : 0;
             if (a < g.a_gran)              // last round: lanes past the image stay masked
-                dma16(wsrc + 4 * sg, __builtin_amdgcn_readfirstlane(lds_addr(lds4 + k * NT + (tid & ~63))));
+                dma16(wsrc + 16 * sg, __builtin_amdgcn_readfirstlane(lds_addr(lds4 + k * NT + (tid & ~63))));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         for (int k = 0; k < g.n_inst; ++k) {
             const int a = k * NT + tid;
-            const long long s = W0 + 4LL * sample_granule(g, a);
-            uint32_t w[4];
+            const long long s = W0 + (long long)SPG * sample_granule(g, a);
+            uint4 v;
+            if constexpr (IN == IN_I16) {
+                uint32_t w[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long long si = s + u;
-                w[u] = (si >= g.lo_valid && si < g.hi_valid) ? src[si] : 0u;
+                for (int u = 0; u < 4; ++u) {
+                    const long long si = s + u;
+                    w[u] = (si >= g.lo_valid && si < g.hi_valid) ? ((const uint32_t *)src)[si] : 0u;
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                const float4 f = fetch_pair_checked<IN>(g, src, s);
+                v = __builtin_bit_cast(uint4, f);
             }
-            if (a < g.a_gran) lds4[a] = make_uint4(w[0], w[1], w[2], w[3]);
+            if (a < g.a_gran) lds4[a] = v;
         }
     }
     __syncthreads();
 
     float2 acc[R];
-    walk<4, R>(g, lds4, gtab, tid, acc);
-    if (g.swap_iq) {                       // Q-first input: real taps, so swapping the sums is exact
+    walk<SPG, R, IN == IN_REAL>(g, lds4, gtab, tid, acc);
+    if (IN == IN_I16 && g.swap_iq) {       // Q-first input: real taps, so swapping the sums is exact
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = make_float2(acc[r].y, acc[r].x);
     }
@@ -755,9 +768,15 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         return hipGetLastError();
     }
     if (p->raw) {
-        SDR_OPT_IN(fir_raw_kernel<R>);
-        fir_raw_kernel<R><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>((const uint32_t *)in, out,
-                                                                        p->d_gtab, g);
+#define SDR_RAW(INK)                                                                             \
+    do {                                                                                         \
+        SDR_OPT_IN((fir_raw_kernel<R, INK>));                                                    \
+        fir_raw_kernel<R, INK><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, g); \
+    } while (0)
+        if (!p->rawf) SDR_RAW(IN_I16);
+        else if (p->input == SDR_IN_CF32) SDR_RAW(IN_CF32);
+        else SDR_RAW(IN_REAL);
+#undef SDR_RAW
         return hipGetLastError();
     }
     const unsigned nb = (unsigned)(g.total_tiles < p->stream_blocks ? g.total_tiles : p->stream_blocks);

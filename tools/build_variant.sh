@@ -8,7 +8,7 @@ tag=$1; src=$2; shift 2
 name=$(basename "$src" .hip)
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Isdr_amd/csrc"
 case $name in
-fir*) F="$F -mllvm -amdgpu-atomic-optimizer-strategy=None" ;;
+fir_mfma_i8) F="$F -mllvm -amdgpu-atomic-optimizer-strategy=None -fno-slp-vectorize" ;;
 fft) F="$F -fno-slp-vectorize" ;;
 fft_wave) F="$F -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp" ;;
 esac

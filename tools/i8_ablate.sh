@@ -11,7 +11,7 @@ build)
   mkdir -p tools/exp
   hipcc $F -DSDR_MEASUREMENT_BUILD -c sdr_amd/csrc/lib.hip -o tools/exp/lib_meas.o
   for v in $VARS; do
-    ( hipcc $F -mllvm -amdgpu-atomic-optimizer-strategy=None -DSDR_MEASUREMENT_BUILD -DSDR_I8_ABLATE=$v -c sdr_amd/csrc/fir_mfma_i8.hip -o tools/exp/fir_abl$v.o
+    ( hipcc $F -mllvm -amdgpu-atomic-optimizer-strategy=None -fno-slp-vectorize -DSDR_MEASUREMENT_BUILD -DSDR_I8_ABLATE=$v -c sdr_amd/csrc/fir_mfma_i8.hip -o tools/exp/fir_abl$v.o
       objs=""
       for o in sdr_amd/build/*.o; do
         case $(basename $o .o) in

@@ -796,7 +796,8 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                             for (int w = 0; w < 4; ++w)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const int other = __builtin_amdgcn_mov_dpp(acci[w][r], 0xB1, 0xF, 0xF, true);
+                                    int other = __builtin_amdgcn_mov_dpp(acci[w][r], 0xB1, 0xF, 0xF, true);
+                                    asm volatile("" : "+v"(other));
                                     acc[w][r] = (j & 1) ? acc[w][r] + other : acc[w][r] - other;
                                 }
                         }

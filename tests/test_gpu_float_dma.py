@@ -1,4 +1,5 @@
-"""WIP: pipeline 7 (float tiles filled by LDS-DMA) against the oracle."""
+"""Pipeline 7 (float tiles filled by LDS-DMA, one tile per workgroup; complex or real float input without mixer:
+the af::fir call shape of the FM receiver, bladerf_fm_demod.cpp:288-294) against the oracle, every geometry."""
 import numpy as np
 import pytest
 

@@ -185,8 +185,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->pipeline == 5 && !i8_possible) { delete p; sdr::set_error("pipeline 5 needs int16 or int8 input without mixer"); return SDR_EINVAL; }
     const bool ksplit_possible = d->input == SDR_IN_F32_REAL && d->mode != SDR_MODE_FM;
     // float input without mixer: the DMA'd image is the float tile (fir_raw_kernel<R, IN_CF32 | IN_REAL>)
-    const bool rawf_possible = (d->input == SDR_IN_CF32 || d->input == SDR_IN_F32_REAL) && d->mix_fr == 0.0 && !chan_mix;
-    if (d->pipeline == 7 && !rawf_possible) { delete p; sdr::set_error("pipeline 7 needs complex or real float input without mixer"); return SDR_EINVAL; }
+    // (real input takes its mixer along: it lives in the complex taps and one phasor per output)
+    const bool rawf_possible = ((d->input == SDR_IN_CF32 && d->mix_fr == 0.0) || d->input == SDR_IN_F32_REAL) && !chan_mix;
+    if (d->pipeline == 7 && !rawf_possible) { delete p; sdr::set_error("pipeline 7 needs complex float input without mixer, or real float input"); return SDR_EINVAL; }
     if (d->pipeline == 6 && !ksplit_possible) { delete p; sdr::set_error("pipeline 6 needs real float input and a mode other than FM"); return SDR_EINVAL; }
     // The planar kernel (float planes, convert once) is an explicit choice only: beyond the int8
     // matrix kernel's window it is 8-12 % ahead of the raw tile at D = 8 and 10 but 1.4-1.8x behind

@@ -446,6 +446,17 @@ fir_raw_kernel(const void *__restrict__ in, void *__restrict__ outv,
     }
 
     const long long m0 = M0 + (long long)tid * R;
+    if (IN == IN_REAL && g.mix_fr != 0.0 && g.mode != SDR_MODE_ENV) {
+        // real input with a mixer: the taps are complex (h[i] e^{-jwi}, built by the plan) and the output takes the
+        // mixer's phasor at its own sample, phase reduced in double (as fir_stream_kernel does; none for the envelope)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double ph = g.mix_fr * (double)((m0 + r) * g.D);
+            float2 P;
+            sincospif(2.0f * (float)(ph - rint(ph)), &P.y, &P.x);
+            acc[r] = cmulf(acc[r], P);
+        }
+    }
     float2 ynext = make_float2(0.f, 0.f);
     if (g.mode == SDR_MODE_FM) {
         float2 *ybuf = (float2 *)(smem + (size_t)g.a_gran * 16);

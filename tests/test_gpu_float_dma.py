@@ -54,7 +54,19 @@ def test_float_dma_tiles(sdr, oracle, T, D, n, kind):
         else:
             gotr = sdr.FirPlan(h, D, mode=sdr.MODE_REAL, input=inp, pipeline=7, outputs_per_lane=R, threads=NT).execute_host(raw)
             check_linear(gotr, y.real, tag + " real")
-    with pytest.raises(sdr.SdrError):
-        sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp, pipeline=7, mix_fr=0.01)
+    if kind == "cf32":
+        with pytest.raises(sdr.SdrError):
+            sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp, pipeline=7, mix_fr=0.01)
+    else:
+        # real input takes a mixer along (complex taps + one phasor per output): frequency_shift in front of the filter
+        for fr in (0.0371, -0.123):
+            ym = oracle.fir_decimate(oracle.frequency_shift(raw.astype(np.float64), fr), D, h) if n else y
+            for mode, want in ((sdr.MODE_IQ, ym), (sdr.MODE_ENV, np.abs(ym)), (sdr.MODE_REAL, ym.real)):
+                try:
+                    pm = sdr.FirPlan(h, D, mode=mode, input=inp, pipeline=7, mix_fr=fr)
+                except sdr.SdrError as e:
+                    assert "no tile geometry" in str(e), str(e)
+                    continue
+                check_linear(pm.execute_host(raw), want, f"T={T} D={D} n={n} real mixer {fr} mode {mode}")
     with pytest.raises(sdr.SdrError):
         sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=sdr.IN_I16_IQ, pipeline=7)

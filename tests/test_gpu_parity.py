@@ -1288,7 +1288,7 @@ def test_ksplit_kernel_short_real_streams(sdr, oracle, T, D, mix):
     small = sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_F32_REAL, mix_fr=mix, size_hint=124_799)
     big = sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_F32_REAL, mix_fr=mix, size_hint=1 << 28)
     none = sdr.FirPlan(h, D, mode=sdr.MODE_ENV, input=sdr.IN_F32_REAL, mix_fr=mix)
-    long_kernels = ("stream",) if mix != 0.0 else ("stream", "float_dma_tile")     # long streams: a throughput kernel
+    long_kernels = ("stream", "float_dma_tile")     # long streams: a throughput kernel
     assert small.info()["kernel"] == "ksplit" and big.info()["kernel"] in long_kernels and none.info()["kernel"] in long_kernels
     with pytest.raises(sdr.SdrError):
         sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=sdr.IN_F32_REAL, pipeline=6)

@@ -47,6 +47,10 @@ def one_case(rng, case_seed):
                            sdr.IN_CF32, sdr.IN_F32_REAL]))
     if T > 2047:
         n = min(n, 40_000)
+    if case_seed % 7 == 0 and T <= 128:
+        # streams long enough to put several tiles on every workgroup of the persistent kernels (a 1024-output tile
+        # per CU: more than 262 144 outputs) -- the round-3 failure of the int8 matrix kernel needed exactly that
+        n = 300_000 * D + (case_seed * 2654435761) % (1_500_000 if D > 2 else 900_000)
     mix = float(rng.choice([0.0, 0.0, 0.0371, -0.123]))
     pipe = int(rng.choice([0, 0, 0, 1, 2, 3, 5]))
     matrix_ok = mix == 0.0 and kind in (sdr.IN_I16_IQ, sdr.IN_I16_QI, sdr.IN_I8_IQ)

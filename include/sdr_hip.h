@@ -203,12 +203,14 @@ typedef struct sdr_fir_desc {
                              whose input is a tenth of the capture block).  Chosen automatically from
                              size_hint.
                              7 = float tiles filled by LDS-DMA, one tile per workgroup (SDR_IN_CF32 or
-                             SDR_IN_F32_REAL without mixer): float samples need no conversion, so the DMA'd
-                             image is the tile the walk reads -- the af::fir call shape of the FM receiver
-                             (cf_samples block, bladerf_fm_demod.cpp:288-294).  The automatic choice for
-                             complex float input without mixer (1.4-2.2x pipeline 2) and for real float input
-                             at lane strides up to 40 samples; same float32 taps and summation order as
-                             pipeline 2. */
+                             SDR_IN_F32_REAL; no per-channel mixers): float samples need no conversion, so the
+                             DMA'd image is the tile the walk reads -- the af::fir call shape of the FM receiver
+                             (cf_samples block, bladerf_fm_demod.cpp:288-294).  A mixer (mix_fr) is folded into
+                             complex taps h[i]*exp(-j*2*pi*fr*i) plus one phasor per output (phase of the
+                             output's own sample, reduced in double), so mixer outputs are bit-identical under
+                             shards and blocks here.  The automatic choice for complex float input (1.4-2.2x
+                             pipeline 2) and for real float input at lane strides up to 40 samples; without
+                             mixer the same float32 taps and summation order as pipeline 2. */
     int count_rule;       /* enum sdr_count_rule; 0 = the polyphase_decimate rule */
     long long size_hint;  /* 0 = unknown; else the input samples a launch will typically see.  Geometry is
                              chosen for long streams by default; with a hint that says "short" (fewer lane

@@ -378,13 +378,30 @@ __device__ __forceinline__ void walk_touch(const uint4 (&v)[U], const float (&t)
                      "s"(t[k + 5]), "s"(t[k + 6]), "s"(t[k + 7]));
 }
 
-template <int SPG, int R, int U, bool REALT>
-__device__ __forceinline__ void walk_fma(const uint4 (&v)[U], const float (&t)[(REALT ? 2 : 1) * SPG * R * U],
+// TAPS: 0 = real taps on complex samples (the plain filter), 1 = complex taps on REAL samples (real input, the mixer
+// folded into the taps), 2 = complex taps on complex samples (complex float input with a mixer, fir_raw_kernel)
+template <int SPG, int R, int U, int TAPS>
+__device__ __forceinline__ void walk_fma(const uint4 (&v)[U], const float (&t)[(TAPS ? 2 : 1) * SPG * R * U],
                                          float2 (&acc)[R])
 {
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-        if constexpr (REALT) {
+        if constexpr (TAPS == 2) {
+            static_assert(TAPS != 2 || SPG == 2, "complex taps on complex samples: float2 tiles");
+            // two complex samples, complex taps g = h e^{-jwi}: acc += x * g
+            const float xr[2] = {__uint_as_float(v[k].x), __uint_as_float(v[k].z)};
+            const float xi[2] = {__uint_as_float(v[k].y), __uint_as_float(v[k].w)};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = 2 * ((k * 2 + u) * R + r);
+                    acc[r].x = __fmaf_rn(xr[u], t[i], acc[r].x);
+                    acc[r].x = __fmaf_rn(-xi[u], t[i + 1], acc[r].x);
+                    acc[r].y = __fmaf_rn(xr[u], t[i + 1], acc[r].y);
+                    acc[r].y = __fmaf_rn(xi[u], t[i], acc[r].y);
+                }
+        } else if constexpr (TAPS == 1) {
             // four real samples, complex taps (the mixer folded into them): acc += x * (tr, ti)
             const float x[4] = {__uint_as_float(v[k].x), __uint_as_float(v[k].y), __uint_as_float(v[k].z), __uint_as_float(v[k].w)};
 #pragma unroll
@@ -419,13 +436,13 @@ __device__ __forceinline__ void walk_fma(const uint4 (&v)[U], const float (&t)[(
 
 // s_begin / s_count (steps, both even): the part of the window this call walks -- the whole of it
 // (0, ngran / U) everywhere but in fir_ksplit_kernel, whose four waves take a quarter each.
-template <int SPG, int R, bool PAD, bool REALT>
+template <int SPG, int R, bool PAD, int TAPS>
 __device__ __forceinline__ void walk_p(const FirGeom &g, const uint4 *lds4,
                                        const float *__restrict__ gtab, int tid, float2 (&acc)[R],
                                        int s_begin = 0, int s_count = -1)
 {
     constexpr int U = Walk<SPG, R>::U;
-    constexpr int N = (REALT ? 2 : 1) * Walk<SPG, R>::N;    // floats of taps per step
+    constexpr int N = (TAPS ? 2 : 1) * Walk<SPG, R>::N;    // floats of taps per step
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
     const uint4 *lane_base = lds4 + tid * (g.q + (PAD ? 1 : 0));
@@ -440,23 +457,23 @@ __device__ __forceinline__ void walk_p(const FirGeom &g, const uint4 *lds4,
         walk_load<U, PAD>(vb, lane_base, (s + 1) * U, g);
         walk_taps<N>(tb, gtab + (size_t)(s + 1) * N);
         __builtin_amdgcn_sched_barrier(0);
-        walk_fma<SPG, R, U, REALT>(va, ta, acc);
+        walk_fma<SPG, R, U, TAPS>(va, ta, acc);
         walk_touch<U, N>(vb, tb);
         __builtin_amdgcn_sched_barrier(0);
         walk_load<U, PAD>(va, lane_base, (s + 2) * U, g);      // look-ahead step (zero taps at the end)
         walk_taps<N>(ta, gtab + (size_t)(s + 2) * N);
         __builtin_amdgcn_sched_barrier(0);
-        walk_fma<SPG, R, U, REALT>(vb, tb, acc);
+        walk_fma<SPG, R, U, TAPS>(vb, tb, acc);
     }
 }
 
-template <int SPG, int R, bool REALT = false>
+template <int SPG, int R, int TAPS = 0>
 __device__ __forceinline__ void walk(const FirGeom &g, const uint4 *lds4,
                                      const float *__restrict__ gtab, int tid, float2 (&acc)[R],
                                      int s_begin = 0, int s_count = -1)
 {
-    if (g.pad) walk_p<SPG, R, true, REALT>(g, lds4, gtab, tid, acc, s_begin, s_count);
-    else walk_p<SPG, R, false, REALT>(g, lds4, gtab, tid, acc, s_begin, s_count);
+    if (g.pad) walk_p<SPG, R, true, TAPS>(g, lds4, gtab, tid, acc, s_begin, s_count);
+    else walk_p<SPG, R, false, TAPS>(g, lds4, gtab, tid, acc, s_begin, s_count);
 }
 
 __device__ __forceinline__ float2 mix(float2 x, double fr, long long s)

@@ -185,9 +185,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     if (d->pipeline == 5 && !i8_possible) { delete p; sdr::set_error("pipeline 5 needs int16 or int8 input without mixer"); return SDR_EINVAL; }
     const bool ksplit_possible = d->input == SDR_IN_F32_REAL && d->mode != SDR_MODE_FM;
     // float input without mixer: the DMA'd image is the float tile (fir_raw_kernel<R, IN_CF32 | IN_REAL>)
-    // (real input takes its mixer along: it lives in the complex taps and one phasor per output)
-    const bool rawf_possible = ((d->input == SDR_IN_CF32 && d->mix_fr == 0.0) || d->input == SDR_IN_F32_REAL) && !chan_mix;
-    if (d->pipeline == 7 && !rawf_possible) { delete p; sdr::set_error("pipeline 7 needs complex float input without mixer, or real float input"); return SDR_EINVAL; }
+    // (a mixer goes along: it lives in complex taps and one phasor per output)
+    const bool rawf_possible = (d->input == SDR_IN_CF32 || d->input == SDR_IN_F32_REAL) && !chan_mix;
+    if (d->pipeline == 7 && !rawf_possible) { delete p; sdr::set_error("pipeline 7 needs complex or real float input (one mixer at most, no per-channel mixers)"); return SDR_EINVAL; }
     if (d->pipeline == 6 && !ksplit_possible) { delete p; sdr::set_error("pipeline 6 needs real float input and a mode other than FM"); return SDR_EINVAL; }
     // The planar kernel (float planes, convert once) is an explicit choice only: beyond the int8
     // matrix kernel's window it is 8-12 % ahead of the raw tile at D = 8 and 10 but 1.4-1.8x behind
@@ -496,7 +496,9 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
     // gtab[j][r] = h[D*r + Tback - j]  (tap that window offset j contributes to output r);
     // rows past the window (padding + look-ahead step) stay zero
     const size_t rows = (size_t)(best.ngran + best.look) * p->spg;
-    const bool real_tile = (!p->raw || p->rawf) && p->input == SDR_IN_F32_REAL;
+    // complex tap table (two floats per tap, the mixer folded in): real input on the float kernels, and complex float
+    // input with a mixer on the DMA tile
+    const bool real_tile = ((!p->raw || p->rawf) && p->input == SDR_IN_F32_REAL) || (p->rawf && p->input == SDR_IN_CF32 && p->mix_fr != 0.0);
     std::vector<float> gt(rows * p->R * (real_tile ? 2 : 1), 0.0f);
     for (size_t j = 0; j < rows; ++j)
         for (int r = 0; r < p->R; ++r) {

@@ -387,7 +387,9 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 // IN = IN_CF32 / IN_REAL (plan `pipeline` = 7): float input without mixer needs no conversion at all, so the
 // DMA'd image IS the float tile the walk reads (two complex or four real samples per 16-byte granule) --
 // no register prefetch, no LDS stores, one tile per workgroup under the hardware dispatcher.
-template <int R, int IN>
+// CT (complex float input only): complex taps -- the plan's mixer folded into them, g[i] = h[i] e^{-jwi}; the output
+// takes the mixer's phasor at its own sample, as for real input.
+template <int R, int IN, bool CT = false>
 __global__ void __launch_bounds__(256)
 fir_raw_kernel(const void *__restrict__ in, void *__restrict__ outv,
                const float *__restrict__ gtab, const FirGeom g)
@@ -439,15 +441,15 @@ fir_raw_kernel(const void *__restrict__ in, void *__restrict__ outv,
     __syncthreads();
 
     float2 acc[R];
-    walk<SPG, R, IN == IN_REAL>(g, lds4, gtab, tid, acc);
+    walk<SPG, R, (IN == IN_REAL ? 1 : (CT ? 2 : 0))>(g, lds4, gtab, tid, acc);
     if (IN == IN_I16 && g.swap_iq) {       // Q-first input: real taps, so swapping the sums is exact
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = make_float2(acc[r].y, acc[r].x);
     }
 
     const long long m0 = M0 + (long long)tid * R;
-    if (IN == IN_REAL && g.mix_fr != 0.0 && g.mode != SDR_MODE_ENV) {
-        // real input with a mixer: the taps are complex (h[i] e^{-jwi}, built by the plan) and the output takes the
+    if ((IN == IN_REAL || CT) && g.mix_fr != 0.0 && g.mode != SDR_MODE_ENV) {
+        // input with a mixer: the taps are complex (h[i] e^{-jwi}, built by the plan) and the output takes the
         // mixer's phasor at its own sample, phase reduced in double (as fir_stream_kernel does; none for the envelope)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -785,8 +787,12 @@ hipError_t launch_r(const sdr_fir_plan *p, hipStream_t st, const void *in, void 
         fir_raw_kernel<R, INK><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, g); \
     } while (0)
         if (!p->rawf) SDR_RAW(IN_I16);
-        else if (p->input == SDR_IN_CF32) SDR_RAW(IN_CF32);
-        else SDR_RAW(IN_REAL);
+        else if (p->input == SDR_IN_CF32) {
+            if (p->mix_fr != 0.0) {
+                SDR_OPT_IN((fir_raw_kernel<R, IN_CF32, true>));
+                fir_raw_kernel<R, IN_CF32, true><<<dim3(8u * (unsigned)g.tiles_per_xcd, n_ch), p->NT, p->lds_bytes, st>>>(in, out, p->d_gtab, g);
+            } else SDR_RAW(IN_CF32);
+        } else SDR_RAW(IN_REAL);
 #undef SDR_RAW
         return hipGetLastError();
     }

@@ -54,19 +54,24 @@ def test_float_dma_tiles(sdr, oracle, T, D, n, kind):
         else:
             gotr = sdr.FirPlan(h, D, mode=sdr.MODE_REAL, input=inp, pipeline=7, outputs_per_lane=R, threads=NT).execute_host(raw)
             check_linear(gotr, y.real, tag + " real")
-    if kind == "cf32":
-        with pytest.raises(sdr.SdrError):
-            sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp, pipeline=7, mix_fr=0.01)
-    else:
-        # real input takes a mixer along (complex taps + one phasor per output): frequency_shift in front of the filter
-        for fr in (0.0371, -0.123):
-            ym = oracle.fir_decimate(oracle.frequency_shift(raw.astype(np.float64), fr), D, h) if n else y
-            for mode, want in ((sdr.MODE_IQ, ym), (sdr.MODE_ENV, np.abs(ym)), (sdr.MODE_REAL, ym.real)):
-                try:
-                    pm = sdr.FirPlan(h, D, mode=mode, input=inp, pipeline=7, mix_fr=fr)
-                except sdr.SdrError as e:
-                    assert "no tile geometry" in str(e), str(e)
-                    continue
-                check_linear(pm.execute_host(raw), want, f"T={T} D={D} n={n} real mixer {fr} mode {mode}")
+    # a mixer goes along (complex taps + one phasor per output): frequency_shift in front of the filter
+    for fr in (0.0371, -0.123):
+        ym = oracle.fir_decimate(oracle.frequency_shift(raw.astype(np.complex128 if kind == "cf32" else np.float64), fr), D, h) if n else y
+        modes = [(sdr.MODE_IQ, ym), (sdr.MODE_ENV, np.abs(ym))] + ([(sdr.MODE_REAL, ym.real)] if kind == "real" else [])
+        for mode, want in modes:
+            try:
+                pm = sdr.FirPlan(h, D, mode=mode, input=inp, pipeline=7, mix_fr=fr)
+            except sdr.SdrError as e:
+                assert "no tile geometry" in str(e), str(e)
+                continue
+            check_linear(pm.execute_host(raw), want, f"T={T} D={D} n={n} {kind} mixer {fr} mode {mode}")
+        if kind == "cf32" and ym.size > 1:
+            try:
+                pm = sdr.FirPlan(h, D, mode=sdr.MODE_FM, input=inp, pipeline=7, mix_fr=fr)
+            except sdr.SdrError:
+                continue
+            check_fm(pm.execute_host(raw), oracle.polar_discriminator(ym, 1 / TWO_PI), ym, 1 / TWO_PI, f"T={T} D={D} n={n} cf32 mixer {fr} fm", good_rel=None)
+    with pytest.raises(sdr.SdrError):
+        sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=inp, pipeline=7, mix_fr_channels=[0.01, 0.02])
     with pytest.raises(sdr.SdrError):
         sdr.FirPlan(h, D, mode=sdr.MODE_IQ, input=sdr.IN_I16_IQ, pipeline=7)

@@ -58,7 +58,7 @@ def one_case(rng, case_seed):
         pipe = 0
     if (mix != 0.0 or kind not in (sdr.IN_I16_IQ, sdr.IN_I16_QI)) and pipe not in (0, 2, 5):
         pipe = 0
-    if mix == 0.0 and kind in (sdr.IN_CF32, sdr.IN_F32_REAL) and pipe == 0 and case_seed % 3 == 0:
+    if kind in (sdr.IN_CF32, sdr.IN_F32_REAL) and pipe == 0 and case_seed % 3 == 0:
         pipe = 7                                     # the DMA-filled float tile, pinned (also an automatic choice)
     h = random_taps(rng, T, D)
     scale = float(rng.choice([1 / TWO_PI, 0.75, -1.0]))

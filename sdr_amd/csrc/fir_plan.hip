@@ -363,7 +363,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         Geometry gm;
         bool ok = make_geometry(p->T, p->D, 4, 64, 4, false, &gm, false, false, 8);
         if (ok) {
-            gm.lds_bytes = gm.a_gran * 16 + 4 * 64 * 4 * 8;
+            gm.lds_bytes = gm.a_gran * 16 > 4 * 64 * 4 * 8 ? gm.a_gran * 16 : 4 * 64 * 4 * 8;    // tile, then the partial sums in its place
             ok = gm.lds_bytes <= 160 * 1024;
         }
         if (ok) { best = gm; bestR = 4; bestNT = 64; best_raw = false; p->ksplit = true; }

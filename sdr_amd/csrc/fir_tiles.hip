@@ -308,7 +308,9 @@ fir_stream_kernel(const void *__restrict__ in, void *__restrict__ outv,
 // QUARTER of the window for all 64 lanes; the four partial sums meet in LDS and are added in a fixed
 // order (quarter 0 first), so an output's value does not depend on the tiling or on the shard.  Four
 // times as many, four times shorter chains.  Same byte model as the streaming kernel.
-// LDS: [tile (a_gran float4) | partial sums (4 x 64*R float2)].  No discriminator (the successor of a
+// LDS: the tile (a_gran float4), then -- in the same memory -- the partial sums (4 x 64*R float2): a smaller
+// workgroup image puts eight workgroups on a CU instead of six (APT stage 2 at cfg5's size: 1 747 tiles in one
+// round of 2 048 slots instead of one and a bit of 1 536).  No discriminator (the successor of a
 // lane's last output lives in another lane's partial sums; the modes real input is used with --
 // envelope, IQ, real -- do not need it).
 // ---------------------------------------------------------------------------------------------
@@ -319,7 +321,7 @@ fir_ksplit_kernel(const float *__restrict__ in, void *__restrict__ outv,
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = (float4 *)smem;
-    float2 *part = (float2 *)(smem + (size_t)g.a_gran * 16);
+    float2 *part = (float2 *)smem;                 // the partial sums reuse the tile's memory (behind a barrier)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = (int)blockIdx.y * g.tiles_per_ch + (int)blockIdx.x;
@@ -337,6 +339,7 @@ fir_ksplit_kernel(const float *__restrict__ in, void *__restrict__ outv,
     const int quarter = g.ngran / U / 4;           // even (host pads the window to a multiple of 8 steps)
     float2 acc[R];
     walk<4, R, true>(g, (const uint4 *)tile, gtab, lane, acc, wave * quarter, quarter);
+    __syncthreads();                               // every wave has finished reading the tile
 #pragma unroll
     for (int r = 0; r < R; ++r) part[(wave * 64 + lane) * R + r] = acc[r];
     __syncthreads();

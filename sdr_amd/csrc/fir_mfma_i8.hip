@@ -384,6 +384,108 @@ __device__ __noinline__ I8Ys<RH> i8_zero_fix(I8Chan c, long long m0, long long s
     return v;
 }
 
+template <int RH, bool S8>
+__device__ __forceinline__ void i8_finish_zfix(const FirGeom &g, void *__restrict__ outv, float2 (&y)[RH], float2 ynext, int ch,
+                                               long long M0, int o0, const uint32_t *__restrict__ in, const float *__restrict__ ftaps);
+
+// The discriminator of a tile's outputs, written operation by operation ACROSS the lane's RH outputs.  A lone wave
+// issues a dependent vector instruction every 6-9 cycles, and hipcc keeps the source order of independent chains:
+// written as RH calls of discriminate() the lane's arctangents ran one after the other (four dependent chains of
+// ~36 instructions: 1 450 cycles per tile in the matrix waves of a long-filter phase, a quarter of it, with the
+// matrix pipe idle); operation-major they overlap in the vector pipeline.  The arithmetic is discriminate() /
+// atan2_finite() operation for operation (fir_common.h), so the bits are those of every other kernel.
+// (Tried in round 3 and not kept: issuing these operations between the MFMAs of the next tile's k loop -- one
+// step per unit of seven MFMAs, sched_group_barrier -- gains nothing on windows of up to eight steps, which the
+// sample stream bounds, and spills 43 registers on twelve-step windows, whose matrix waves have none to spare.)
+template <int RH, int NCB>
+struct I8FinFM {
+    static constexpr int kOps = 26;
+    float yr[RH + 1], yi[RH + 1];          // y[0..RH-1] and the successor of the last
+    float re[RH], im[RH], mx[RH], mn[RH], s[RH], q[RH], u[RH];
+    int ch, o0;
+    long long M0;
+
+    __device__ __forceinline__ void load(const FirGeom &g, const float *ybuf, int par, int F, int t)
+    {
+        constexpr int TILE = 128 * NCB;
+        o0 = RH * F;
+        const int o2 = o0 + RH < TILE ? o0 + RH : TILE - 1;
+        const float *pa = ybuf + par * NCB * (4 * kI8PartSlots) + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
+        const float *pb = ybuf + par * NCB * (4 * kI8PartSlots) + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
+        ch = i8_tile_channel(g, t);
+        M0 = g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile;
+        if constexpr (RH == 4) {
+            const float4 qi = *(const float4 *)pa, qq = *(const float4 *)(pa + 4 * 33);
+            yr[0] = qi.x; yr[1] = qi.y; yr[2] = qi.z; yr[3] = qi.w;
+            yi[0] = qq.x; yi[1] = qq.y; yi[2] = qq.z; yi[3] = qq.w;
+        } else {
+            static_assert(RH == 2, "two or four outputs per finishing lane");
+            const float2 qi = *(const float2 *)pa, qq = *(const float2 *)(pa + 4 * 33);
+            yr[0] = qi.x; yr[1] = qi.y; yi[0] = qq.x; yi[1] = qq.y;
+        }
+        yr[RH] = pb[0]; yi[RH] = pb[4 * 33];
+    }
+
+    // operation I of the chain, for all RH outputs (the order of discriminate() and atan2_finite())
+    template <int I>
+    __device__ __forceinline__ void op()
+    {
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+            // y1 = y[r+1] = (a, b), y0 = y[r] = (c, -e)
+            const float a = yr[r + 1], b = yi[r + 1], c = yr[r], e = -yi[r];
+            if constexpr (I == 0) q[r] = b * e;
+            else if constexpr (I == 1) re[r] = __fmaf_rn(a, c, -q[r]);
+            else if constexpr (I == 2) q[r] = b * c;
+            else if constexpr (I == 3) im[r] = __fmaf_rn(a, e, q[r]);
+            else if constexpr (I == 4) mx[r] = fmaxf(fabsf(re[r]), fabsf(im[r]));
+            else if constexpr (I == 5) mn[r] = fminf(fabsf(re[r]), fabsf(im[r]));
+            else if constexpr (I == 6) q[r] = (mx[r] < 1e-30f) ? 1.8446744e19f : 1.0f;
+            else if constexpr (I == 7) mx[r] *= q[r];
+            else if constexpr (I == 8) mn[r] *= q[r];
+            else if constexpr (I == 9) q[r] = __builtin_amdgcn_rcpf(mx[r]);
+            else if constexpr (I == 10) s[r] = mn[r] * q[r];
+            else if constexpr (I == 11) s[r] = __fmaf_rn(__fmaf_rn(-mx[r], s[r], mn[r]), q[r], s[r]);
+            else if constexpr (I == 12) s[r] = (mx[r] == 0.0f) ? 0.0f : s[r];
+            else if constexpr (I == 13) q[r] = s[r] * s[r];                                   // t
+            else if constexpr (I == 14) u[r] = __fmaf_rn(0.00282363896258175373077393f, q[r], -0.0159569028764963150024414f);
+            else if constexpr (I == 15) u[r] = __fmaf_rn(u[r], q[r], 0.0425049886107444763183594f);
+            else if constexpr (I == 16) u[r] = __fmaf_rn(u[r], q[r], -0.0748900920152664184570312f);
+            else if constexpr (I == 17) u[r] = __fmaf_rn(u[r], q[r], 0.106347933411598205566406f);
+            else if constexpr (I == 18) u[r] = __fmaf_rn(u[r], q[r], -0.142027363181114196777344f);
+            else if constexpr (I == 19) u[r] = __fmaf_rn(u[r], q[r], 0.199926957488059997558594f);
+            else if constexpr (I == 20) u[r] = __fmaf_rn(u[r], q[r], -0.333331018686294555664062f);
+            else if constexpr (I == 21) s[r] = __fmaf_rn(s[r] * q[r], u[r], s[r]);            // atan(mn/mx)
+            else if constexpr (I == 22) s[r] = (fabsf(im[r]) > fabsf(re[r])) ? 1.57079632679489661923f - s[r] : s[r];
+            else if constexpr (I == 23) s[r] = (__float_as_uint(re[r]) >> 31) ? 3.14159265358979323846f - s[r] : s[r];
+            else if constexpr (I == 24) s[r] = __uint_as_float(__float_as_uint(s[r]) | (__float_as_uint(im[r]) & 0x80000000u));
+            // (I == 25: the scale, in store())
+        }
+    }
+
+    __device__ __forceinline__ void run() { static_for_ops<0, kOps - 1>(); }
+    template <int I, int N>
+    __device__ __forceinline__ void static_for_ops()
+    {
+        if constexpr (I < N) { op<I>(); static_for_ops<I + 1, N>(); }
+    }
+
+    template <bool S8>
+    __device__ __forceinline__ void store(const FirGeom &g, void *__restrict__ outv, const uint32_t *__restrict__ in,
+                                          const float *__restrict__ ftaps)
+    {
+        float v[RH];
+#pragma unroll
+        for (int r = 0; r < RH; ++r) v[r] = g.scale * s[r];
+        const long long tile_end = M0 + g.per_tile;
+        store_values<RH>(g, outv, ch, M0 + (long long)o0, v, tile_end < g.out_end ? tile_end : g.out_end);
+        float2 y[RH];
+#pragma unroll
+        for (int r = 0; r < RH; ++r) y[r] = make_float2(yr[r], yi[r]);
+        i8_finish_zfix<RH, S8>(g, outv, y, make_float2(yr[RH], yi[RH]), ch, M0, o0, in, ftaps);
+    }
+};
+
 // Finishing of tile t (computed in the previous phase, outputs in ybuf[par]):
 // finishing lane F takes outputs RH*F .. RH*F + RH-1 of the tile and, for the discriminator, their
 // successor.  A column block (128 outputs) is kI8PartSlots float4 slots, component 0's outputs in order
@@ -414,6 +516,15 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
         }
         return;
     }
+    if constexpr (RH >= 2) {
+        if (g.mode == SDR_MODE_FM) {
+            I8FinFM<RH, NCB> fs;
+            fs.load(g, ybuf, par, F, t);
+            fs.run();
+            fs.template store<S8>(g, outv, in, ftaps);
+            return;
+        }
+    }
     float2 y[RH], ynext;
     if constexpr (RH == 4) {
         const float4 qi = *(const float4 *)pa, qq = *(const float4 *)(pa + 4 * 33);
@@ -432,6 +543,14 @@ __device__ __forceinline__ void i8_finish(const FirGeom &g, void *__restrict__ o
     // address keep their order): a branch in front of the discriminator would split the block the
     // scheduler overlaps the LDS reads and the arctangents in.
     store_outputs<RH>(g, outv, ch, M0 + (long long)o0, y, ynext, M0 + g.per_tile);
+    i8_finish_zfix<RH, S8>(g, outv, y, ynext, ch, M0, o0, in, ftaps);
+}
+
+// (see i8_finish) the second look at exactly-zero y behind the stores
+template <int RH, bool S8>
+__device__ __forceinline__ void i8_finish_zfix(const FirGeom &g, void *__restrict__ outv, float2 (&y)[RH], float2 ynext, int ch,
+                                               long long M0, int o0, const uint32_t *__restrict__ in, const float *__restrict__ ftaps)
+{
     if (g.zfix) {
         // the matrix waves' combination never yields -0, so "both components zero" is "both words zero":
         // one OR per output, one unsigned minimum over three of them (in this kernel every vector

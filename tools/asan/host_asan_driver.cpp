@@ -28,7 +28,7 @@ int main()
         for (int D : Ds)
             for (int input = 0; input <= 4; ++input)
                 for (int mode = 0; mode <= 3; ++mode)
-                    for (int pipe = 0; pipe <= 5; ++pipe) {
+                    for (int pipe = 0; pipe <= 7; ++pipe) {
                         if (pipe != 0 && (rnd() & 3)) continue;          // thin out the explicit choices
                         std::vector<double> h(T);
                         for (int i = 0; i < T; ++i) h[i] = std::sin(0.37 * i + 0.1) / (1.0 + 0.01 * i);

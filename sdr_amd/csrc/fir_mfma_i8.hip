@@ -397,9 +397,12 @@ __device__ __forceinline__ void i8_finish_zfix(const FirGeom &g, void *__restric
 // (Tried in round 3 and not kept: issuing these operations between the MFMAs of the next tile's k loop -- one
 // step per unit of seven MFMAs, sched_group_barrier -- gains nothing on windows of up to eight steps, which the
 // sample stream bounds, and spills 43 registers on twelve-step windows, whose matrix waves have none to spare.)
-template <int RH, int NCB>
+// TURN (complex taps, i8_finish_cpx): the product y[m+1] conj(y[m]) is turned by the channel's constant E = e^{jwD}
+// before the arctangent.
+template <int RH, int NCB, bool TURN = false>
 struct I8FinFM {
     static constexpr int kOps = 26;
+    float Ex = 1.f, Ey = 0.f;
     float yr[RH + 1], yi[RH + 1];          // y[0..RH-1] and the successor of the last
     float re[RH], im[RH], mx[RH], mn[RH], s[RH], q[RH], u[RH];
     int ch, o0;
@@ -463,7 +466,31 @@ struct I8FinFM {
         }
     }
 
-    __device__ __forceinline__ void run() { static_for_ops<0, kOps - 1>(); }
+    __device__ __forceinline__ void run()
+    {
+        static_for_ops<0, 4>();
+        if constexpr (TURN) {
+            // tr = fma(re, E.x, -(im * E.y)) + 0, ti = fma(re, E.y, im * E.x) + 0 (the + 0 washes a -0 out: the product
+            // of two exact zeros stays (+0, +0), see i8_finish_cpx)
+#pragma unroll
+            for (int r = 0; r < RH; ++r) q[r] = im[r] * Ey;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) mx[r] = __fmaf_rn(re[r], Ex, -q[r]) + 0.0f;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) q[r] = im[r] * Ex;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) im[r] = __fmaf_rn(re[r], Ey, q[r]) + 0.0f;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) re[r] = mx[r];
+        }
+        static_for_ops<4, kOps - 1>();
+    }
+    // the scaled angles (after run())
+    __device__ __forceinline__ void values(float scale, float (&v)[RH]) const
+    {
+#pragma unroll
+        for (int r = 0; r < RH; ++r) v[r] = scale * s[r];
+    }
     template <int I, int N>
     __device__ __forceinline__ void static_for_ops()
     {
@@ -640,8 +667,16 @@ __device__ __forceinline__ void i8_finish_cpx(const FirGeom &g, void *__restrict
         return g.scale * atan2_finite(ti, tr);
     };
     float v[RH];
+    {
+        // operation-major over the lane's outputs (I8FinFM): the same arithmetic as `turned`, chains overlapped
+        I8FinFM<RH, NCB, true> fs;
+        fs.Ex = E.x; fs.Ey = E.y;
 #pragma unroll
-    for (int r = 0; r < RH; ++r) v[r] = turned(r + 1 < RH ? y[r + 1] : ynext, y[r]);
+        for (int r = 0; r < RH; ++r) { fs.yr[r] = y[r].x; fs.yi[r] = y[r].y; }
+        fs.yr[RH] = ynext.x; fs.yi[RH] = ynext.y;
+        fs.run();
+        fs.values(g.scale, v);
+    }
     store_values<RH>(g, outv, ch, m0, v, out_end);
     unsigned mn = __float_as_uint(ynext.x) | __float_as_uint(ynext.y);
 #pragma unroll

@@ -132,6 +132,45 @@ __device__ __forceinline__ void dft64(cf (&x)[64], const W64Table &T)
     });
 }
 
+// The last radix-4 stage of pass 2 leaves its outputs as (re, re) and (im, im) pairs of two bins -- the same four
+// v_pk_add_f32 with other half selections -- so that |X|^2 of two bins is one v_pk_mul_f32 + one v_pk_fma_f32
+// (instead of two v_pk_mul_f32 + two v_add_f32 on (re, im) pairs: 64 vector instructions less per frame, in a
+// kernel bound by vector-instruction issue).  p02 = |y0|^2, |y2|^2;  p13 = |y1|^2, |y3|^2.
+__device__ __forceinline__ void dft4_power(cf x0, cf x1, cf x2, cf x3, cf &p02, cf &p13)
+{
+    const cf t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = csub(x1, x3);
+    cf re02, im02, re13, im13;
+    // y0 = t0 + t2, y2 = t0 - t2
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(re02) : "v"(t0), "v"(t2));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(im02) : "v"(t0), "v"(t2));
+    // y1 = t1 - j t3 = (t1.x + t3.y, t1.y - t3.x), y3 = t1 + j t3 = (t1.x - t3.y, t1.y + t3.x)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(re13) : "v"(t1), "v"(t3));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(im13) : "v"(t1), "v"(t3));
+    p02 = re02 * re02;
+    p13 = re13 * re13;
+    asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(p02) : "v"(im02), "v"(p02));
+    asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(p13) : "v"(im13), "v"(p13));
+}
+
+// dft64 whose last stage is dft4_power: pw[k1] = |X|^2 of bins k1, k1 + 32; pw[16 + k1] = bins k1 + 16, k1 + 48
+__device__ __forceinline__ void dft64_power(cf (&x)[64], const W64Table &T, cf (&pw)[32])
+{
+    cf u[4][16];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+        cf t[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) t[n1] = x[4 * n1 + n2];
+        dft<16>(t);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) u[n2][k] = t[k];
+    }
+    static_for<0, 16>([&](auto K) {
+        constexpr int k1 = decltype(K)::value;
+        dft4_power(u[0][k1], tw64<k1>(u[1][k1], T), tw64<2 * k1>(u[2][k1], T), tw64<3 * k1>(u[3][k1], T), pw[k1], pw[16 + k1]);
+    });
+}
+
 // TWO = false: four waves per CU (one per SIMD), whole 64 x 66 images, A/B twiddles in registers.
 // TWO = true:  eight waves per CU (two per SIMD, 256 registers each): the image is half as tall, the
 //              transpose runs in two rounds plus one half-wave register swap (see there), and the A/B
@@ -288,19 +327,22 @@ fft4096_wave_kernel(const uint32_t *__restrict__ iq, const float *__restrict__ w
             }
         }
         // ---- pass 2 -------------------------------------------------------------------------------
-        if constexpr (!(SDR_FFT_ABLATE & 2)) dft64(x, T);
+        cf pw[32];
+        if constexpr (!(SDR_FFT_ABLATE & 2)) dft64_power(x, T, pw);
+        else {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) pw[k] = x[k] * x[k + 32];
+        }
         // the prefetched half frame has had the whole frame to arrive; waiting for it here, BEFORE this
         // frame's stores are issued, keeps the wait from covering the stores (vmcnt counts in issue order)
 #pragma unroll
         for (int t = 0; t < 32; ++t) asm volatile("" ::"v"(nxt[t]));
-        // ---- |X|^2 -> dB, fft-shifted row: register k2 holds bin lane + 64 k2 -----------------------
+        // ---- |X|^2 -> dB, fft-shifted row: pw[i] holds bins lane + 64 i and lane + 64 (i + 32)
 #pragma unroll
-        for (int k2 = 0; k2 < 64; k2 += 2) {
-            const cf s0 = x[k2] * x[k2], s1 = x[k2 + 1] * x[k2 + 1];
-            cf p = {s0.x + s0.y, s1.x + s1.y};
-            p = cf{__log2f(p.x), __log2f(p.y)} * 3.01029995663981195f;
-            __builtin_nontemporal_store(p.x, &row[64 * ((k2 + 32) & 63)]);
-            __builtin_nontemporal_store(p.y, &row[64 * ((k2 + 33) & 63)]);
+        for (int i = 0; i < 32; ++i) {
+            const cf p = cf{__log2f(pw[i].x), __log2f(pw[i].y)} * 3.01029995663981195f;
+            __builtin_nontemporal_store(p.x, &row[64 * (i + 32)]);       // bin lane + 64 i
+            __builtin_nontemporal_store(p.y, &row[64 * i]);              // bin lane + 64 (i + 32)
         }
     }
     if constexpr (SDR_FFT_ABLATE & 32) {

@@ -13,6 +13,7 @@ SHAPES = [  # log2n, T, D, mode, input, pipeline
     (30, 64, 10, 1, 0, 0), (28, 64, 10, 1, 0, 0), (28, 64, 10, 2, 0, 0), (28, 64, 10, 0, 0, 0), (26, 511, 10, 1, 0, 0), (28, 511, 10, 1, 0, 0),
     (28, 200, 10, 1, 0, 0), (28, 101, 5, 1, 0, 0), (28, 64, 4, 1, 0, 0), (28, 300, 25, 1, 0, 0), (28, 64, 10, 1, 4, 0), (28, 511, 10, 1, 4, 0),
     (28, 64, 10, 1, 0, 1),
+    (28, "fft4096", 2048, 0, 0, 0),          # index 13: the cfg4 waterfall (4096-point Blackman frames, hop 2048) instead of a FIR
 ]
 
 
@@ -28,6 +29,17 @@ def child():
     pick = [int(x) for x in os.environ.get("AB_SHAPES", "").split(",") if x] or list(range(len(SHAPES)))
     for (l2, T, D, mode, inp, pipe) in [SHAPES[i] for i in pick]:
         n = 1 << l2
+        if T == "fft4096":
+            p = sdr_amd.FftPlan(4096, D, sdr_amd.window("blackman", 4096))
+            frames = p.frame_count(n)
+            d_db = sdr_amd.DevBuf(frames * 4096 * 4)
+            for _ in range(6):
+                p.time_dev(d_in, n, d_db, 20)
+            ms = sorted(p.time_dev(d_in, n, d_db, 10) for _ in range(5))
+            out.append({"shape": [l2, T, D, mode, inp, pipe], "ms_min": ms[0], "ms_med": ms[2], "kernel": "fft4096"})
+            d_db.free()
+            p.destroy()
+            continue
         h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
         p = sdr_amd.FirPlan(h, D, mode=mode, input=inp, pipeline=pipe)
         # warm the clocks: batches until two agree within 1 %

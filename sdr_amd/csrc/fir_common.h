@@ -77,7 +77,8 @@ struct sdr_fir_plan {
     float4 *d_atab = nullptr;   // its A-operand table
     bool ksplit = false;    // fir_ksplit_kernel (real input, short streams: taps split over the four waves of a workgroup)
     bool mfma_i8 = false;   // fir_mfma_i8_kernel (byte-split Toeplitz GEMM on the int8 matrix pipe, persistent)
-    bool cpx = false;       // ... with complex taps per channel (the channelizer's mixers folded into the taps)
+    int cpx = 0;            // ... with complex taps per channel (the channelizer's mixers folded into the taps): 1 = the
+                            // output's component in the matrix product's columns, 2 = in its rows (even D; fir_mfma_i8.hip)
     float2 *d_chan_e = nullptr;   // its per-channel output-step phasors exp(j*2*pi*fr*D)
     uint4 *d_atab8 = nullptr;   // its A-operand table (tap digits)
     uint4 *d_btab8 = nullptr;   // 128 * row sums of the digits, per matrix wave

@@ -611,31 +611,67 @@ __device__ __forceinline__ void i8_finish_zfix(const FirGeom &g, void *__restric
 //                  ONE exact zero goes through i8_zero_fix, which brings back the reference's y
 //   IQ, real part  y itself is the output: the lane's first phasor from its phase (reduced in double), the
 //                  following ones by E
-template <int RH, int NCB, bool S8>
+// The finishing waves' view of the channel they are finishing: the turn E = e^{jwD} and the NCO frequency, fetched
+// when the channel CHANGES (a workgroup walks a contiguous run of tiles: a handful of times per launch) and waited
+// for there.  Read where they are used -- once per tile -- the wait for the two values is a wait for everything the
+// wave has in flight: in the helper waves the samples just requested, a whole memory round trip per tile.
+struct I8ChanE {
+    int ch = -1;            // table entry (chan_index) the values belong to
+    float ex = 1.f, ey = 0.f;
+    double fr = 0.0;
+    __device__ __forceinline__ void select(const FirGeom &g, int launch_ch)
+    {
+        const int c = __builtin_amdgcn_readfirstlane((int)chan_index(g, launch_ch));
+        if (c != ch) {
+            ch = c;
+            const float2 e = g.chan_tab[c];
+            const double f = g.chan_fr[c];
+            // (through readfirstlane: the values have arrived when the branch ends, and live in scalar registers)
+            ex = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e.x)));
+            ey = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e.y)));
+            fr = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(f)), __builtin_amdgcn_readfirstlane(__double2loint(f)));
+        }
+    }
+};
+
+// ROWS: ybuf holds (re, im) pairs in output order (the row layout of complex taps, CPX = 2 below) instead of one
+// run of 128 values per component and column block.
+template <int RH, int NCB, bool S8, bool ROWS>
 __device__ __forceinline__ void i8_finish_cpx(const FirGeom &g, void *__restrict__ outv, const float *ybuf, int par, int F, int t,
-                                              const uint32_t *__restrict__ in, const float *__restrict__ ftaps)
+                                              const uint32_t *__restrict__ in, const float *__restrict__ ftaps, I8ChanE &ce)
 {
     constexpr int TILE = 128 * NCB;
+    constexpr int PER = ROWS ? 2 : 1;                           // floats per output within a column block's run
     const int o0 = RH * F, o2 = o0 + RH < TILE ? o0 + RH : TILE - 1;
-    const float *pa = ybuf + par * NCB * (4 * kI8PartSlots) + (o0 >> 7) * (4 * kI8PartSlots) + (o0 & 127);
-    const float *pb = ybuf + par * NCB * (4 * kI8PartSlots) + (o2 >> 7) * (4 * kI8PartSlots) + (o2 & 127);
+    const float *pa = ybuf + par * NCB * (4 * kI8PartSlots) + (o0 >> 7) * (4 * kI8PartSlots) + PER * (o0 & 127);
+    const float *pb = ybuf + par * NCB * (4 * kI8PartSlots) + (o2 >> 7) * (4 * kI8PartSlots) + PER * (o2 & 127);
     const int ch = i8_tile_channel(g, t);
     const long long M0 = g.tile0 + (long long)(t - ch * g.tiles_per_ch) * g.per_tile;
     const long long m0 = M0 + (long long)o0;
     const long long tile_end = M0 + g.per_tile;
     const long long out_end = tile_end < g.out_end ? tile_end : g.out_end;
-    const float2 E = g.chan_tab[chan_index(g, ch)];
+    ce.select(g, ch);
+    const float2 E = make_float2(ce.ex, ce.ey);
     float2 y[RH], ynext;
-    if constexpr (RH == 4) {
+    static_assert(RH == 2 || RH == 4, "complex-tap tiles have 1024 outputs");
+    if constexpr (ROWS) {
+        const float4 q0 = *(const float4 *)pa;
+        y[0] = make_float2(q0.x, q0.y); y[1] = make_float2(q0.z, q0.w);
+        if constexpr (RH == 4) {
+            const float4 q1 = *(const float4 *)(pa + 4);
+            y[2] = make_float2(q1.x, q1.y); y[3] = make_float2(q1.z, q1.w);
+        }
+        ynext = *(const float2 *)pb;
+    } else if constexpr (RH == 4) {
         const float4 qi = *(const float4 *)pa, qq = *(const float4 *)(pa + 4 * 33);
         y[0] = make_float2(qi.x, qq.x); y[1] = make_float2(qi.y, qq.y);
         y[2] = make_float2(qi.z, qq.z); y[3] = make_float2(qi.w, qq.w);
+        ynext = make_float2(pb[0], pb[4 * 33]);
     } else {
-        static_assert(RH == 2, "complex-tap tiles have 1024 outputs");
         const float2 qi = *(const float2 *)pa, qq = *(const float2 *)(pa + 4 * 33);
         y[0] = make_float2(qi.x, qq.x); y[1] = make_float2(qi.y, qq.y);
+        ynext = make_float2(pb[0], pb[4 * 33]);
     }
-    ynext = make_float2(pb[0], pb[4 * 33]);
     if (g.mode == SDR_MODE_ENV) {
         float v[RH];
 #pragma unroll
@@ -644,7 +680,7 @@ __device__ __forceinline__ void i8_finish_cpx(const FirGeom &g, void *__restrict
         return;
     }
     if (g.mode == SDR_MODE_IQ || g.mode == SDR_MODE_REAL) {
-        const double ph = g.chan_fr[chan_index(g, ch)] * (double)(m0 * g.D);
+        const double ph = ce.fr * (double)(m0 * g.D);
         float2 P;
         sincospif(2.0f * (float)(ph - rint(ph)), &P.y, &P.x);
         float2 *dst = (float2 *)outv + (long long)ch * g.out_stride + (m0 - g.out_begin);
@@ -709,7 +745,16 @@ __device__ __forceinline__ void i8_finish_cpx(const FirGeom &g, void *__restrict
 // and Q columns of a group sit in adjacent lanes).  A workgroup takes a CONTIGUOUS run of tiles, so it
 // changes channel -- and reloads 32 KB of digits -- a handful of times per launch.  Windows of up to
 // four steps (NS = 4), tiles of 1024 outputs, static order.
-template <int NS, int NCB, int PRE, bool S8, bool DYN, bool CPX = false>
+// CPX = 2 (even decimation factors): the same complex taps with the output's component in the ROWS of the matrix
+// product instead of its columns.  Row i of a block = (output i / 2 of a group of EIGHT outputs, component i % 2), the 64
+// k values of a step = 32 window offsets x (I plane | Q plane), and the taps carry the signs:
+//   A[(o, re)][(k, I)] = Gr[t]   A[(o, re)][(k, Q)] = -Gi[t]   A[(o, im)][(k, I)] = Gi[t]   A[(o, im)][(k, Q)] = Gr[t],  t = D o + Tb - k
+//   B (samples): lane (j, kq) holds bytes 8 D grp + 32 ks + 16 (kq / 2) + 0..15 of plane (kq % 2, hi | lo), grp = 16 cb + j
+//   C:           lane (j, kq) holds (re, im) of outputs 2 kq and 2 kq + 1 of group grp
+// One set of accumulators, no exchange between lanes, and a group's window is Tb + 7 D + 1 samples instead of Tb + 15 D
+// + 1: at 64 taps / 10 five steps of seven products per column block (35) where the column form runs four steps of
+// fourteen (56) and then 64 cross-lane additions.  (Odd D: the 16-byte sample reads at 8 D grp would be misaligned.)
+template <int NS, int NCB, int PRE, bool S8, bool DYN, int CPX = 0>
 __global__ void __launch_bounds__(512, 1)
 fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                    const uint4 *__restrict__ atab, const uint4 *__restrict__ btab, const FirGeom g,
@@ -733,7 +778,9 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     int *tq = (int *)(smem + 2 * buf_bytes + 2 * NCB * kI8PartSlots * 16 + (NS > 8 ? kI8MaxSteps * 1024 : 0));
     unsigned q_drawn = 0;                                      // (lane 0 of wave 0) the place drawn in the previous phase
     unsigned G = gridDim.x, xcd = blockIdx.x & 7;
-    static_assert(!CPX || (NS == 4 && NCB == 8 && !DYN), "complex taps: four steps, 1024-output tiles, static order");
+    static_assert(!CPX || (NCB == 8 && !DYN), "complex taps: 1024-output tiles, static order");
+    static_assert(CPX != 1 || NS == 4, "complex taps in column form: four steps");
+    static_assert(CPX != 2 || NS == 4 || NS == 8, "complex taps in row form: up to eight steps of 32 window offsets");
     // static order: tile n of this workgroup is n * tstep + slot0 -- every G-th tile, or (complex taps) a
     // contiguous run of ceil(total / G) tiles
     const int run = (g.total_tiles + (int)G - 1) / (int)G;
@@ -761,9 +808,19 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         else return (n >= 0 && n < n_t) ? n * tstep + slot0 : -1;
     };
     // who finishes: 0 the matrix waves, 1 the helper waves, 2 both (one half of the tile each; see the matrix waves)
-    constexpr int FIN = (NCB == 8 && PRE <= (S8 ? 6 : 4)) ? 2 : 0;
+    // Measured (same box, 2^28 samples, FIN 0 / 1 / 2 in every instantiation, tools/ab_libs.py): wide tiles of windows
+    // the sample stream bounds (64/10, 200/10, 101/5) lose 6-13 % to any finishing in the helper waves; twelve-step
+    // windows of int16 samples gain 3-4.5 % from halves (511/10) when the finishing comes BEFORE the helper waves' next
+    // request (FIN_FIRST: whatever wait the finishing holds then does not cover the samples just requested).  Complex
+    // taps in row form, 64/10: int16 pairs 0.263 / 0.272 / 0.271 ms with FIN 0 / 1 / 2, int8 pairs 0.180 / 0.172 / 0.169.
+    // A wave issues one instruction in four cycles whatever its kind, so a role's time is its instruction count, scalar
+    // bookkeeping included, and every wave that finishes pays the finishing's fixed part (~270 instructions) again.
+    constexpr bool LONG16 = !CPX && NS == 12 && !S8 && NCB == 8 && PRE > 4;
+    constexpr int FIN = CPX == 2 ? (S8 ? 2 : 0) : (NCB == 8 && (PRE <= (S8 ? 6 : 4) || LONG16)) ? 2 : 0;
+    constexpr bool FIN_FIRST = CPX == 2 || LONG16;
     I8Clock clk;
     int n_ph = 0;
+    I8ChanE chan_e;                                            // (complex taps) the channel being finished
 
     if (matrix) {
         // four matrix waves, one per SIMD; wave w takes column blocks CBW*w .. CBW*w + CBW-1 of every tile
@@ -776,7 +833,8 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         // would be 192 registers and leave no room for the epilogue: the lowest digit, which only one of
         // the seven products reads, then lives in LDS and is fetched with the samples (144 registers).
         constexpr bool A0_LDS = NS > 8;
-        constexpr int NP = CPX ? 2 : 1;                        // tap parts: real only | real, imaginary
+        constexpr int NP = CPX == 1 ? 2 : 1;                   // tap parts: real only | real, imaginary (column form)
+        constexpr int KSB = CPX == 2 ? 32 : 64;                // sample bytes of a plane per step
         i32x4 a[NS][NP][4];
         uint4 *a0lds = (uint4 *)(ybuf + 2 * NCB * kI8PartSlots);
         int ch_loaded = CPX ? -1 : 0;                          // complex taps: the channel whose digits are resident
@@ -812,8 +870,9 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         f32x4 bias = (S8 || CPX) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, btab[lane]);
         if (DYN && !S8) asm volatile("" ::"v"(bias));          // (waited for here, like the digits above)
         // hi plane of component j&1, this lane's group within a column block, step 0
-        const int bofs = (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq + CBW * wave * (16 * g.D * 8);
         const int cb_bytes = 16 * g.D * 8;                     // between column blocks
+        const int bofs = (CPX == 2 ? (kq & 1) * plane_bytes + 8 * g.D * j + 16 * (kq >> 1)
+                                   : (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq) + CBW * wave * cb_bytes;
         // each matrix wave also finishes its own quarter of the tile before the last (R outputs per lane).
         // Measured alternatives, all within 2 %: finishing in the helper waves (they are then the longer
         // role), half in each, and its arithmetic interleaved with the MFMAs by sched_group_barrier --
@@ -845,7 +904,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
             // the tile before the last
             if (FIN != 1 && t_fin >= 0 && !(SDR_I8_ABL & 4))
             {
-                if constexpr (CPX) i8_finish_cpx<(FIN == 2 ? R / 2 : R), NCB, S8>(g, outv, (const float *)ybuf, p & 1, tid, t_fin, in, ftaps);
+                if constexpr (CPX) i8_finish_cpx<(FIN == 2 ? R / 2 : R), NCB, S8, CPX == 2>(g, outv, (const float *)ybuf, p & 1, tid, t_fin, in, ftaps, chan_e);
                 else i8_finish<(FIN == 2 ? R / 2 : R), NCB, S8>(g, outv, (const float *)ybuf, p & 1, tid, t_fin, in, ftaps);
             }
             if (DYN && wave == 0 && lane == 0) q_drawn = i8_draw(qctr, 1u);
@@ -873,22 +932,22 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 // units of (column block, step), samples requested PD units ahead (int8 samples: a unit
                 // is four MFMAs, 64 cycles, so the LDS round trip needs the longer lead)
                 constexpr int UNITS = CBW * NS;
-                constexpr int PD = CPX ? (S8 ? 2 : 1) : (S8 ? 4 : 2), NB = PD + 1;
+                constexpr int PD = CPX == 1 ? (S8 ? 2 : 1) : (S8 ? 4 : 2), NB = PD + 1;
                 i32x4 b[NB][3];                                // [buffer][hi, lo, lowest tap digit]
 #pragma unroll
                 for (int u = 0; u < PD && u < UNITS; ++u) {
-                    const unsigned char *bp = bbase + (u / NS) * cb_bytes + 64 * (u % NS);
+                    const unsigned char *bp = bbase + (u / NS) * cb_bytes + KSB * (u % NS);
                     b[u][0] = as_i32x4(*(const uint4 *)bp);
                     if (!S8) b[u][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
                     if (A0_LDS) b[u][2] = as_i32x4(a0lds[(u % NS) * 64 + lane]);
                 }
                 i32x4 acc[4];                                  // weights 2^8 .. 2^32
-                i32x4 acci[CPX ? 4 : 1];                       // complex taps: the imaginary part's sums
+                i32x4 acci[CPX == 1 ? 4 : 1];                  // complex taps in column form: the imaginary part's sums
 #pragma unroll
                 for (int u = 0; u < UNITS; ++u) {
                     const int cb = u / NS, ks = u % NS;
                     if (u + PD < UNITS && !(SDR_I8_ABL & 32)) {
-                        const unsigned char *bp = bbase + ((u + PD) / NS) * cb_bytes + 64 * ((u + PD) % NS);
+                        const unsigned char *bp = bbase + ((u + PD) / NS) * cb_bytes + KSB * ((u + PD) % NS);
                         b[(u + PD) % NB][0] = as_i32x4(*(const uint4 *)bp);
                         if (!S8) b[(u + PD) % NB][1] = as_i32x4(*(const uint4 *)(bp + 2 * plane_bytes));
                         if (A0_LDS) b[(u + PD) % NB][2] = as_i32x4(a0lds[((u + PD) % NS) * 64 + lane]);
@@ -897,7 +956,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                     if (ks == 0) {
 #pragma unroll
                         for (int w = 0; w < 4; ++w) acc[w] = i32x4{0, 0, 0, 0};
-                        if constexpr (CPX) {
+                        if constexpr (CPX == 1) {
 #pragma unroll
                             for (int w = 0; w < 4; ++w) acci[w] = i32x4{0, 0, 0, 0};
                         }
@@ -911,7 +970,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                             acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][1], xh, acc[1], 0, 0, 0);
                             acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][2], xh, acc[2], 0, 0, 0);
                             acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][3], xh, acc[3], 0, 0, 0);
-                            if constexpr (CPX) {
+                            if constexpr (CPX == 1) {
 #pragma unroll
                                 for (int w = 0; w < 4; ++w) acci[w] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][w], xh, acci[w], 0, 0, 0);
                             }
@@ -927,7 +986,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, xh, acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][1], xh, acc[1], 0, 0, 0);
                         acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][0][2], xh, acc[2], 0, 0, 0);
-                        if constexpr (CPX) {
+                        if constexpr (CPX == 1) {
                             acci[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][1], xl, acci[0], 0, 0, 0);
                             acci[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][2], xl, acci[1], 0, 0, 0);
                             acci[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks][NP - 1][3], xl, acci[2], 0, 0, 0);
@@ -942,7 +1001,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         // y = yscale * sum of 2^(8w) * acc[w] (the common 2^8 sits in yscale): the only
                         // floating-point step, a fixed sequence on exact integers.  Balanced digits: the
                         // top term carries the value, the rest is a correction -- nothing cancels.
-                        if constexpr (CPX) {
+                        if constexpr (CPX == 1) {
                             // real output (the I column, even lane) = Gr*Xi - Gi*Xq, imaginary (the Q column,
                             // odd lane) = Gr*Xq + Gi*Xi: the other column's "imaginary" sums come from the
                             // adjacent lane (quad_perm 1,0,3,2), exact in int32
@@ -967,7 +1026,8 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                         // stored in output order, component 1 starting at slot 33: the helper lanes read
                         // consecutive slots, and the odd component offset keeps these stores down to a
                         // two-way bank conflict, which hides behind the store's register transfer
-                        ybuf[(((p - 1) & 1) * NCB + CBW * wave + cb) * kI8PartSlots + (j & 1) * 33 + (j >> 1) * 4 + kq] = rv;
+                        // (row form: (re, im) pairs in output order, 64 consecutive slots per column block)
+                        ybuf[(((p - 1) & 1) * NCB + CBW * wave + cb) * kI8PartSlots + (CPX == 2 ? j * 4 + kq : (j & 1) * 33 + (j >> 1) * 4 + kq)] = rv;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1041,13 +1101,17 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
                 }
             }
             clk.mark(0);
+            auto finish = [&]() {
+                if (FIN != 0 && t_fin >= 0 && !(SDR_I8_ABL & 4))
+                {
+                    if constexpr (CPX) i8_finish_cpx<(FIN == 2 ? NCB / 4 : NCB / 2), NCB, S8, CPX == 2>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin, in, ftaps, chan_e);
+                    else i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB, S8>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin, in, ftaps);
+                }
+            };
+            if constexpr (FIN_FIRST) finish();
             request(t_req, w, tl);
             clk.mark(1);
-            if (FIN != 0 && t_fin >= 0 && !(SDR_I8_ABL & 4))
-            {
-                if constexpr (CPX) i8_finish_cpx<(FIN == 2 ? NCB / 4 : NCB / 2), NCB, S8>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin, in, ftaps);
-                else i8_finish<(FIN == 2 ? NCB / 4 : NCB / 2), NCB, S8>(g, outv, (const float *)ybuf, p & 1, FIN == 2 ? tid : st, t_fin, in, ftaps);
-            }
+            if constexpr (!FIN_FIRST) finish();
             if constexpr (DYN) tq_snap = tq_in;
             clk.arrive();
             lds_only_barrier();
@@ -1179,10 +1243,15 @@ hipError_t sdr::fir::launch_mfma_i8(const sdr_fir_plan *p, hipStream_t st, const
         // octets per lane, so those instantiations do not exist (a wider one would do the same work)
         const int ns = (p->ngran + 3) / 4;
         if (p->cpx) {
-            // complex taps per channel: four steps, tiles of 1024 outputs, contiguous runs of tiles
-#define SDR_I8C(PRE, S8) SDR_I8K(4, 8, PRE, S8, false, true)
-            if (p->input == SDR_IN_I8_IQ) { if (pre <= 4) SDR_I8C(4, true); else if (pre <= 6) SDR_I8C(6, true); else SDR_I8C(8, true); }
-            else { if (pre <= 4) SDR_I8C(4, false); else if (pre <= 6) SDR_I8C(6, false); else SDR_I8C(8, false); }
+            // complex taps per channel: tiles of 1024 outputs, contiguous runs of tiles; row form (even D) with up to
+            // four or eight steps of 32 window offsets, column form with four steps of 64
+#define SDR_I8C(NS, PRE, S8, FORM) SDR_I8K(NS, 8, PRE, S8, false, FORM)
+#define SDR_I8CP(NS, S8, FORM) do { if (pre <= 4) SDR_I8C(NS, 4, S8, FORM); else if (pre <= 6) SDR_I8C(NS, 6, S8, FORM); else SDR_I8C(NS, 8, S8, FORM); } while (0)
+#define SDR_I8CF(NS, FORM) do { if (p->input == SDR_IN_I8_IQ) SDR_I8CP(NS, true, FORM); else SDR_I8CP(NS, false, FORM); } while (0)
+            if (p->cpx == 2) { if (p->ngran <= 4) SDR_I8CF(4, 2); else SDR_I8CF(8, 2); }
+            else SDR_I8CF(4, 1);
+#undef SDR_I8CF
+#undef SDR_I8CP
 #undef SDR_I8C
         } else
         if (p->R == 4) { if (ns <= 1) SDR_I8(4, 8); else if (ns == 2) SDR_I8(8, 8); else SDR_I8(12, 8); }

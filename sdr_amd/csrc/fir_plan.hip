@@ -279,10 +279,13 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         if (d->outputs_per_lane || d->threads) { delete p; sdr::set_error("pipeline 5 chooses its own geometry (512 lanes): leave outputs_per_lane and threads 0"); return SDR_EINVAL; }
         Geometry gm{};
         gm.Tback = roundup(p->T - 1, 4);
-        const int W = gm.Tback + 15 * p->D + 1;
-        const int nks = (W + 63) / 64;
-        if (chan_mix && nks > 4) {
-            // complex taps double the digit registers: four steps (256 samples) at most
+        // complex taps (the channelizer), even D: the row form of fir_mfma_i8_kernel -- groups of eight outputs, steps
+        // of 32 window offsets (x two components), up to eight of them; odd D: the column form, four steps of 64
+        const bool rows = chan_mix && p->D % 2 == 0;
+        const int W = gm.Tback + (rows ? 7 : 15) * p->D + 1;
+        const int nks = rows ? (W + 31) / 32 : (W + 63) / 64;
+        if (chan_mix && nks > (rows ? 8 : 4)) {
+            // complex taps double the digit registers: 256 samples at most
             if (!auto_i8) { sdr::set_error("pipeline 5 with per-channel mixers: window of %d samples exceeds 256 (decim=%d taps=%d)", W, p->D, p->T); delete p; return SDR_EINVAL; }
             fits = false;
         }
@@ -296,7 +299,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         // else 512 outputs
         int ncb = 0;
         for (int cand = 8; cand >= 4 && !ncb; cand -= 4) {
-            const long long s_tile = (long long)p->D * 16 * (8 * cand - 1) + 64LL * 4 * ns;   // last group's base + every wave's steps
+            const long long s_tile = rows ? (long long)p->D * 8 * (16 * cand - 1) + 32LL * (nks <= 4 ? 4 : 8)
+                                          : (long long)p->D * 16 * (8 * cand - 1) + 64LL * 4 * ns;   // last group's base + every wave's steps
             // byte planes, 1 B per sample; the offset between the I and Q planes is chosen so that the
             // 16-lane groups of the matrix waves' ds_read_b128 (MI355X_MICROARCH.md, LDS) meet no bank twice
             static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
@@ -311,7 +315,8 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
                     int per_slot[16] = {0}, worst = 0;
                     for (int li = 0; li < 16; ++li) {
                         const int lane = grp[gi][li], jj = lane & 15, kq = lane >> 4;
-                        const int addr = (jj & 1) * (base + skew) + 16 * p->D * (jj >> 1) + 16 * kq;
+                        const int addr = rows ? (kq & 1) * (base + skew) + 8 * p->D * jj + 16 * (kq >> 1)
+                                              : (jj & 1) * (base + skew) + 16 * p->D * (jj >> 1) + 16 * kq;
                         const int slot = (addr / 16) & 15;
                         if (++per_slot[slot] > worst) worst = per_slot[slot];
                     }
@@ -321,7 +326,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             }
             const int plane = base + best_skew;
             // two tile buffers + two tiles of outputs + the lowest tap digits of a 12-step window
-            const int lds = 2 * 4 * plane + 2 * cand * kI8PartSlots * 16 + (ns > 2 ? kI8MaxSteps * 1024 : 0) + 64;   // + the tile queue
+            const int lds = 2 * 4 * plane + 2 * cand * kI8PartSlots * 16 + (!rows && ns > 2 ? kI8MaxSteps * 1024 : 0) + 64;   // + the tile queue
             // the helper lanes hold the staged tile in registers, at most 8 octets of samples each
             const bool wide = (s_tile / 4 + 1) / 2 > 256 * 8;
             if ((lds > 160 * 1024 || wide) && cand > 4) continue;
@@ -344,7 +349,7 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
         if (fits) {
             best = gm; bestR = ncb / 2; bestNT = 256; best_raw = true;   // 256 finishing lanes, two or four outputs each
             p->mfma_i8 = true;
-            p->cpx = chan_mix;
+            p->cpx = chan_mix ? (rows ? 2 : 1) : 0;
         }
     }
     // Short real-input streams (the plan's size hint): when the streaming kernel would put fewer than two
@@ -617,7 +622,55 @@ extern "C" int sdr_fir_plan_create(const sdr_fir_desc *d, sdr_fir_plan **out)
             std::memcpy(&u, bf, 16);
             return u;
         };
-        if (!p->cpx) {
+        if (p->cpx == 2) {
+            // the channelizer in row form: per channel [step][digit][lane], sixteen digits of
+            // A[(o, c)][(k, c')], row i = lane % 16 = (output o = i / 2, component c = i % 2), k = 32 ks + 16 (kq / 2) + b,
+            // c' = kq % 2 (kq = lane / 16), t = D o + Tb - k:  (re, I) Gr[t]  (re, Q) -Gi[t]  (im, I) Gi[t]  (im, Q) Gr[t]
+            // with g[i] = h[i] exp(-j 2 pi fr i) (phase reduced in double); the bias from the rows' digit sums as ever
+            const int NSC = p->ngran <= 4 ? 4 : 8;             // the kernel instantiation's steps (launch_mfma_i8)
+            at8.assign((size_t)p->n_chan_mix * NSC * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
+            bt8.assign((size_t)p->n_chan_mix * 64, make_uint4(0u, 0u, 0u, 0u));
+            chan_e.resize((size_t)p->n_chan_mix * 2);
+            std::vector<long long> qr(p->T), qi(p->T);
+            p->zfix = true;      // the discriminator's shortcut (a constant turn of the product) needs every exact zero looked at
+            for (int c = 0; c < p->n_chan_mix; ++c) {
+                const double fr = d->mix_fr_channels[c];
+                for (int i = 0; i < p->T; ++i) {
+                    const double ph = fr * (double)i, f = ph - std::rint(ph);
+                    qr[i] = std::llround(std::ldexp(d->taps[i] * std::cos(2.0 * M_PI * f), F));
+                    qi[i] = std::llround(std::ldexp(-d->taps[i] * std::sin(2.0 * M_PI * f), F));
+                }
+                std::vector<int> rs(64, 0);                        // [digit][row]
+                uint4 *dst = at8.data() + (size_t)c * NSC * 4 * 64;
+                for (int ks = 0; ks < NSC; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int row = lane & 15, kq = lane >> 4, o = row >> 1, co = row & 1, ci = kq & 1;
+                        unsigned char dg[4][16];
+                        for (int b = 0; b < 16; ++b) {
+                            const long long k = 32LL * ks + 16 * (kq >> 1) + b;
+                            const long long t = (long long)p->D * o + p->Tback - k;
+                            long long r = 0;
+                            if (t >= 0 && t < p->T) r = co == ci ? qr[t] : (co ? qi[t] : -qi[t]);
+                            for (int di = 0; di < 4; ++di) {
+                                const long long dgt = ((r + 128) & 255) - 128;       // balanced digit in [-128, 127]
+                                dg[di][b] = (unsigned char)(dgt & 255);
+                                rs[(size_t)di * 16 + row] += (int)dgt;
+                                r = (r - dgt) / 256;
+                            }
+                        }
+                        for (int di = 0; di < 4; ++di) {
+                            uint32_t v[4];
+                            for (int u = 0; u < 4; ++u)
+                                v[u] = dg[di][4 * u] | ((uint32_t)dg[di][4 * u + 1] << 8) | ((uint32_t)dg[di][4 * u + 2] << 16) | ((uint32_t)dg[di][4 * u + 3] << 24);
+                            dst[((size_t)ks * 4 + di) * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                for (int lane = 0; lane < 64; ++lane) bt8[(size_t)c * 64 + lane] = bias_of(rs.data(), lane);
+                const double phd = fr * (double)p->D, fd = phd - std::rint(phd);
+                chan_e[2 * (size_t)c] = (float)std::cos(2.0 * M_PI * fd);
+                chan_e[2 * (size_t)c + 1] = (float)std::sin(2.0 * M_PI * fd);
+            }
+        } else if (!p->cpx) {
             std::vector<int> rowsum((size_t)4 * 16, 0);            // [digit][row]
             at8.assign((size_t)kI8MaxSteps * 4 * 64, make_uint4(0u, 0u, 0u, 0u));
             digits_of(q, kI8MaxSteps, 4, at8.data(), rowsum.data());

@@ -1080,7 +1080,7 @@ def test_matrix_kernel_zero_runs(sdr, oracle, T, D, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,T,D", [("i16", 64, 10), ("i16", 101, 5), ("cf32", 64, 10), ("i8", 64, 10), ("qi", 200, 8),
-                                      ("i16", 511, 10)])
+                                      ("i16", 511, 10), ("i16", 180, 8), ("qi", 32, 4), ("i8", 96, 6), ("i16", 199, 8), ("i8", 33, 14)])
 def test_channelizer_per_channel_mixers(sdr, oracle, kind, T, D):
     """The channelizer as SURVEY 8 a7 words BASELINE config 3: one NCO per channel in front of the filter
     (create_freq_rotation / frequency_shift per channel, sdr_functions.h:63-74, bladerf_apt_demod.cpp:476-495;
@@ -1123,8 +1123,9 @@ def test_channelizer_per_channel_mixers(sdr, oracle, kind, T, D):
     for mode, dt, eb in ((sdr.MODE_FM, np.float32, 4), (sdr.MODE_ENV, np.float32, 4), (sdr.MODE_IQ, np.complex64, 8)):
         plan = sdr.FirPlan(h, D, mode=mode, input=inp, mix_fr_channels=frs)
         # integer input with a window of up to 256 samples: the int8 matrix kernel with the mixers folded
-        # into complex taps; else the float-tile kernel with per-channel phasor tables
-        want_kernel = "mfma_i8" if kind != "cf32" and (T - 1 + 3) // 4 * 4 + 15 * D + 1 <= 256 else "stream"
+        # into complex taps (even D: groups of eight outputs, the row form; odd D: of sixteen, the column form);
+        # else the float-tile kernel with per-channel phasor tables
+        want_kernel = "mfma_i8" if kind != "cf32" and (T - 1 + 3) // 4 * 4 + (7 if D % 2 == 0 else 15) * D + 1 <= 256 else "stream"
         assert plan.info()["kernel"] == want_kernel, (plan.info(), want_kernel)
         cnt = plan.out_count(n)
         stride = cnt + 3
@@ -1174,7 +1175,7 @@ def test_channelizer_per_channel_mixers(sdr, oracle, kind, T, D):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,T,D", [("i16", 64, 10), ("i16", 101, 5), ("i8", 64, 10), ("i16", 64, 1)])
+@pytest.mark.parametrize("kind,T,D", [("i16", 64, 10), ("i16", 101, 5), ("i8", 64, 10), ("i16", 64, 1), ("i16", 64, 2), ("i8", 150, 4)])
 def test_channelizer_matrix_kernel_zero_runs(sdr, oracle, kind, T, D):
     """The complex-tap matrix kernel computes z[m] = y[m] e^{-jw mD} and turns the discriminator's product by
     a constant instead of turning every y (i8_finish_cpx).  Where the reference's y is an exact zero -- zero

@@ -81,10 +81,14 @@ def run(name, n, shared, mix=True, emit=True):
     arith = None
     if kern == "mfma_i8":
         # issued int8 matrix work: per tile of 1020 stored outputs 8 column blocks x (k steps of the window) x
-        # 7 byte products (x 2 with complex taps), 16*16*64*2 operations each
-        nks = (((T - 1 + 3) // 4 * 4) + 15 * D + 1 + 63) // 64
+        # 7 byte products, 16*16*64*2 operations each
+        tb = (T - 1 + 3) // 4 * 4
+        if mix and D % 2 == 0:      # complex taps in row form: groups of eight outputs, steps of 32 window offsets x 2 components
+            per_block = (tb + 7 * D + 1 + 31) // 32 * 7
+        else:                       # steps of 64 window offsets; complex taps in column form run every product twice
+            per_block = (tb + 15 * D + 1 + 63) // 64 * (14 if mix else 7)
         tiles = N_CH * ((cnt + 1019) // 1020)
-        tops = tiles * 8 * nks * (14 if mix else 7) * 32768.0 / (ms * 1e-3) / 1e12
+        tops = tiles * 8 * per_block * 32768.0 / (ms * 1e-3) / 1e12
         arith = {"bound": "mfma", "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8, issued)",
                  "frac": round(tops / MFMA_I8_PEAK_TOPS, 4)}
     else:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-role phase clocks of fir_mfma_i8_kernel from a measurement build (SDR_I8_ABLATE bit 8): shader
 cycles per tile that each role works / is parked at the barrier.
-usage: SDRHIP_LIB=<build> i8_stamps.py [log2n [T D [int8]]]"""
+usage: SDRHIP_LIB=<build> i8_stamps.py [log2n [T D [int8|int16 [mix_fr]]]]"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ import sdr_amd  # noqa: E402
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 T, D = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (511, 10)
 s8 = len(sys.argv) > 4 and sys.argv[4] == "int8"
+mix = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
 sdr_amd.init(0)
 print(sdr_amd.capi.build_info())
 n = 1 << log2n
@@ -21,7 +22,7 @@ sdr_amd.capi.synth_fm_i16_dev(d_in, n // 2 if s8 else n, fs=20e6, noise_lsb=8)
 n_out = n // D - 1
 d_out = sdr_amd.DevBuf((n_out + 64 + 8 * 8 * 256 + 64) * 4)
 h = sdr_amd.create_fir_filter(T, 1.0 / D, "hann")
-p = sdr_amd.FirPlan(h, D, mode=1, pipeline=5, input=sdr_amd.IN_I8_IQ if s8 else sdr_amd.IN_I16_IQ)
+p = sdr_amd.FirPlan(h, D, mode=1, pipeline=5, input=sdr_amd.IN_I8_IQ if s8 else sdr_amd.IN_I16_IQ, mix_fr=mix)
 print("T", T, "D", D, "int8 samples" if s8 else "int16 samples", p.info())
 p.time_dev(d_in, n, d_out, 40)
 ms = p.time_dev(d_in, n, d_out, 1)

@@ -873,10 +873,9 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
         const int cb_bytes = 16 * g.D * 8;                     // between column blocks
         const int bofs = (CPX == 2 ? (kq & 1) * plane_bytes + 8 * g.D * j + 16 * (kq >> 1)
                                    : (j & 1) * plane_bytes + 16 * g.D * (j >> 1) + 16 * kq) + CBW * wave * cb_bytes;
-        // each matrix wave also finishes its own quarter of the tile before the last (R outputs per lane).
-        // Measured alternatives, all within 2 %: finishing in the helper waves (they are then the longer
-        // role), half in each, and its arithmetic interleaved with the MFMAs by sched_group_barrier --
-        // MFMA and vector time of a SIMD add up whichever wave issues them.
+        // each matrix wave also finishes its own quarter of the tile before the last (R outputs per lane),
+        // unless FIN (above) gives the helper waves a half or all of it.  Also measured: the finishing's
+        // arithmetic interleaved with the MFMAs by sched_group_barrier (no gain up to eight steps, spills at twelve).
         // Narrow tiles leave the helper waves little to stage: there each role finishes one half of the
         // tile (FIN = 2: 512 finishing lanes).  int16 samples: tiles of up to four octets per helper
         // lane (D <= 7; same box, 2^28 samples: 32/2 0.600 -> 0.557 ms, 255/4 0.408 -> 0.392, 700/4

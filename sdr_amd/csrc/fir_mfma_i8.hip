@@ -815,7 +815,7 @@ fir_mfma_i8_kernel(const uint32_t *__restrict__ in, void *__restrict__ outv,
     // taps in row form, 64/10: int16 pairs 0.263 / 0.272 / 0.271 ms with FIN 0 / 1 / 2, int8 pairs 0.180 / 0.172 / 0.169.
     // A wave issues one instruction in four cycles whatever its kind, so a role's time is its instruction count, scalar
     // bookkeeping included, and every wave that finishes pays the finishing's fixed part (~270 instructions) again.
-    constexpr bool LONG16 = !CPX && NS == 12 && !S8 && NCB == 8 && PRE > 4;
+    constexpr bool LONG16 = !CPX && NS == 12 && !S8 && NCB == 8 && PRE == 6;     // (with eight octets per helper lane the halves spill)
     constexpr int FIN = CPX == 2 ? (S8 ? 2 : 0) : (NCB == 8 && (PRE <= (S8 ? 6 : 4) || LONG16)) ? 2 : 0;
     constexpr bool FIN_FIRST = CPX == 2 || LONG16;
     I8Clock clk;

@@ -1225,6 +1225,42 @@ def test_channelizer_matrix_kernel_zero_runs(sdr, oracle, kind, T, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,D", [(40, 10), (24, 14), (64, 14), (64, 9), (40, 13), (24, 3), (120, 2), (185, 10)])
+@pytest.mark.parametrize("kind", ["i16", "i8"])
+def test_channelizer_matrix_kernel_instantiations(sdr, oracle, kind, T, D):
+    """The complex-tap instantiations of the int8 matrix kernel that test_channelizer_per_channel_mixers does not
+    reach: row form (even D) with four and eight steps, column form (odd D), four / six / eight octets per helper
+    lane, int16 and int8 pairs -- three channels each, discriminator and envelope against the oracle's
+    frequency_shift -> fir_decimate -> demod, over several tiles with a ragged end."""
+    rng = np.random.default_rng(1000 * T + D)
+    n = 3 * 1024 * D + 5 * D + 3
+    if kind == "i8":
+        raw = rng.integers(-128, 128, 2 * n).astype(np.int8)
+        inp, xs = sdr.IN_I8_IQ, oracle.unpack_scale_i8(raw)
+    else:
+        raw = rng.integers(-32768, 32768, 2 * n).astype(np.int16)
+        inp, xs = sdr.IN_I16_IQ, oracle.unpack_scale_i16(raw)
+    h = oracle.create_fir_filter(T, min(0.8 / D, 0.45), "hann")
+    frs = np.array([0.0371, -0.31, 0.4999])
+    ys = [oracle.fir_decimate(oracle.frequency_shift(xs, fr), D, h) for fr in frs]
+    d_in = sdr.DevBuf.from_numpy(raw)
+    for mode in (sdr.MODE_FM, sdr.MODE_ENV):
+        plan = sdr.FirPlan(h, D, mode=mode, input=inp, mix_fr_channels=frs)
+        assert plan.info()["kernel"] == "mfma_i8", plan.info()
+        cnt = plan.out_count(n)
+        d_out = sdr.DevBuf(cnt * frs.size * 4)
+        plan.execute_channels_dev(d_in, n, 0, 0, frs.size, d_out, cnt)
+        sdr.sync()
+        out = d_out.to_numpy(np.float32, cnt * frs.size).reshape(frs.size, cnt)
+        for c, fr in enumerate(frs):
+            tag = f"complex-tap instantiation {kind} {T}/{D} mode {mode} fr {fr}"
+            if mode == sdr.MODE_FM:
+                check_fm(out[c], oracle.polar_discriminator(ys[c], 1 / TWO_PI), ys[c], 1 / TWO_PI, tag, good_rel=None)
+            else:
+                check_linear(out[c], np.abs(ys[c]), tag)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_fft4096_kernel_variants(sdr, oracle, variant):
     """The 4096-point / hop-2048 waterfall has four kernels (sdr_fft_plan_set_variant): one frame per
